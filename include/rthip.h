@@ -1,0 +1,169 @@
+/*
+ * rthip.h -- C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference has no plugin or FFI interface; its de-facto boundary is the wgpu binding
+ * interface of src/shader.wgsl (lines 1-9) driven by two host functions in src/main.rs:
+ * upload_scene (328-353) and frame (356-407).  Each entry point below names the piece of that
+ * boundary it replaces.  Everything is plain C: pointers, sizes, int status.  No exceptions or
+ * panics cross the ABI.
+ *
+ * Status: 0 = OK, negative = error; rthip_last_error(ctx) returns the text (ctx may be NULL
+ * for errors of rthip_create / rthip_device_count).
+ * Threading: a context is bound to one HIP device and is NOT thread-safe; different contexts
+ * may be driven from different threads or processes.
+ * Ownership: input pointers are borrowed for the duration of the call and copied to the
+ * device; outputs are caller-allocated host buffers unless a parameter says "device".
+ * Streams: every context owns one HIP stream; all work is enqueued there and calls that return
+ * data synchronise it.  rthip_set_stream substitutes a caller's stream.
+ */
+#ifndef RTHIP_H
+#define RTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RTHIP_OK = 0,
+    RTHIP_ERR_INVALID = -1,    /* bad argument (null pointer, size mismatch, index out of range) */
+    RTHIP_ERR_HIP = -2,        /* a HIP runtime call failed; text carries hipGetErrorString */
+    RTHIP_ERR_STATE = -3,      /* call order: render before upload_scene / set_frame_uniforms */
+    RTHIP_ERR_NO_DEVICE = -4,  /* no such device ordinal */
+    RTHIP_ERR_UNSUPPORTED = -5 /* a parameter value this build does not implement */
+} rthip_status;
+
+typedef struct rthip_ctx rthip_ctx;
+
+/* The six storage buffers and the environment texture the reference binds at group 1
+ * (shader.wgsl:3-9), as host arrays in the reference's byte layouts; what
+ * Context::upload_scene writes with queue.write_buffer / write_texture (main.rs:330-349). */
+typedef struct {
+    const void*     tris;      uint64_t n_tris;     /* 48 B each  (scene.rs:713-717)  */
+    const void*     tri_exts;                       /* 96 B each  (scene.rs:113-117)  */
+    const void*     nodes;     uint64_t n_nodes;    /* 32 B each  (scene.rs:840-850)  */
+    const void*     prims;     uint32_t n_prims;    /* 240 B each (scene.rs:181-189)  */
+    const uint32_t* texels;    uint64_t n_texels;   /* scene.rs:239, 290-297          */
+    const float*    env;       uint32_t env_w, env_h; /* rgba32f, scene.rs:251, 603-615 */
+} rthip_scene_desc;
+
+/* The reference compiles these into the shader (shader.wgsl:898, 896, 765, 303); the defaults
+ * set by rthip_default_params reproduce it exactly. */
+typedef struct {
+    uint32_t max_bounces;      /* 8: iterations of the bounce loop                         */
+    float    term_prob;        /* 0.5: unconditional termination probability after a hit   */
+    float    aperture_radius;  /* 0.025 world units (camera.aperture is ignored upstream)  */
+    uint32_t stack_depth;      /* 23: traversal stack entries; a push beyond it is dropped
+                                  and the pixel painted (1,1,0), shader.wgsl:306-313, 941  */
+    uint32_t enable_sun;       /* 0: the live shader has no sun (shader.wgsl:916-937)      */
+    uint32_t flags;            /* RTHIP_FLAG_* */
+} rthip_render_params;
+
+#define RTHIP_FLAG_COUNTERS 1u   /* maintain rthip_counters (small cost)                       */
+#define RTHIP_FLAG_TAPS     2u   /* record primary hits + final seeds of the first frame       */
+#define RTHIP_FLAG_TIMING   4u   /* bracket every stage launch with HIP events (rthip_timing)  */
+
+#define RTHIP_MAX_STACK_DEPTH 64u
+
+typedef struct {
+    uint64_t rays;            /* trace() calls (shader.wgsl:598): the unit of the Mrays/s metric */
+    uint64_t prims_visited;   /* primitives whose root box was tested in local space            */
+    uint64_t inner_steps;     /* inner-node steps (two child boxes each), shader.wgsl:496-521   */
+    uint64_t leaf_steps;      /* leaf-node steps, shader.wgsl:458-495                           */
+    uint64_t tri_tests;       /* ray/triangle tests, shader.wgsl:462                            */
+    uint64_t alpha_tests;     /* in-traversal alpha lookups, shader.wgsl:464-487                */
+    uint64_t texel_fetches;   /* texture_data reads, traversal + shading                        */
+    uint64_t shade_calls;     /* handle_surface_hit_brdf calls, shader.wgsl:912                 */
+    uint64_t misses;          /* handle_miss calls, shader.wgsl:904                             */
+    uint64_t kills;           /* paths ended by the termination draw, shader.wgsl:907-909       */
+    uint64_t stack_overflows; /* dropped pushes                                                 */
+    uint64_t paths;           /* camera rays generated                                          */
+} rthip_counters;
+
+#define RTHIP_STAGE_GENERATE 0
+#define RTHIP_STAGE_EXTEND   1
+#define RTHIP_STAGE_SHADE    2
+#define RTHIP_STAGE_RESOLVE  3
+#define RTHIP_NUM_STAGES     4
+
+typedef struct {
+    double   ms[RTHIP_NUM_STAGES];        /* summed kernel time per stage, HIP events       */
+    uint64_t launches[RTHIP_NUM_STAGES];  /* launches per stage                             */
+} rthip_timing;
+
+int  rthip_device_count(void);
+/* Gpu::new + Context::init's buffer creation (gpu.rs:508-590, main.rs:200-221). */
+int  rthip_create(int device_ordinal, rthip_ctx** out);
+void rthip_destroy(rthip_ctx* ctx);
+const char* rthip_last_error(const rthip_ctx* ctx);
+
+/* All later work is enqueued on `hip_stream` (a hipStream_t); NULL restores the context's own
+ * stream.  The caller keeps the stream alive.  No counterpart upstream (single wgpu queue). */
+int rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
+
+/* Context::upload_scene (main.rs:328-353).  Copies and repacks: nodes keep their 32-byte
+ * records and tree, shifted so that sibling pairs are 64-byte aligned; triangles become
+ * (p0, e1, e2) records in the uploaded order. */
+int rthip_upload_scene(rthip_ctx* ctx, const rthip_scene_desc* scene);
+
+/* queue.write_buffer(frame_uniforms_buffer) (main.rs:380): the exact 608 bytes of
+ * FrameUniforms.  Read: scene.camera, res, reject_hist, prim_count; `frame` is overridden by
+ * rthip_render's frame arguments.  A change of res re-allocates the accumulator
+ * (update_resolution, main.rs:79-94) and implies reject_hist = 1. */
+int rthip_set_frame_uniforms(rthip_ctx* ctx, const void* blob608);
+
+void rthip_default_params(rthip_render_params* p);
+
+/* The compute pass of frame() (main.rs:383-393) run n_frames times: frames first_frame,
+ * first_frame + frame_stride, ...  The frame index is the only per-sample RNG key
+ * (shader.wgsl:895); the reference's first dispatch uses frame 1 (main.rs:372).  If
+ * reject_hist is 1 the first frame overwrites the accumulator, and reject_hist is then cleared
+ * (main.rs:403).  Asynchronous: returns once the work is enqueued. */
+int rthip_render(rthip_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                 const rthip_render_params* params);
+
+/* Use caller-owned DEVICE memory (n_pixels * 4 floats, 16-byte aligned) as the accumulator,
+ * e.g. a tensor that a collective library will reduce in place.  NULL returns to a
+ * library-owned buffer.  The `screen` storage buffer of shader.wgsl:6. */
+int rthip_bind_accum(rthip_ctx* ctx, void* device_ptr, uint64_t n_pixels);
+int rthip_accum_device_ptr(rthip_ctx* ctx, void** device_ptr, uint64_t* n_pixels);
+
+/* Read back / restore `screen` (rgb = radiance sum, a = sample count).  The reference never
+ * reads it back; its buffers carry COPY_SRC (gpu.rs:490-493). */
+int rthip_read_accum(rthip_ctx* ctx, float* rgba, uint64_t n_pixels);
+int rthip_write_accum(rthip_ctx* ctx, const float* rgba, uint64_t n_pixels);
+
+/* Parity taps of the FIRST frame of the last rthip_render issued with RTHIP_FLAG_TAPS: per
+ * pixel the primary hit's triangle index (-1 = miss), primitive index, distance, and the RNG
+ * state when the path ended.  Any pointer may be NULL. */
+int rthip_read_taps(rthip_ctx* ctx, int32_t* tri_idx, int32_t* prim_idx, float* t,
+                    uint32_t* final_seed, uint64_t n_pixels);
+
+/* Proof that the device holds the identical tree: the device node array (32-byte records;
+ * capacity in records) and, per uploaded node, its device index. */
+int rthip_read_nodes_device_layout(rthip_ctx* ctx, void* nodes_out, uint64_t capacity,
+                                   uint64_t* n_records);
+int rthip_read_node_index_map(rthip_ctx* ctx, uint32_t* device_index_of_node, uint64_t n_nodes);
+/* Order-preserving triangle map: device triangle i is uploaded triangle out[i]. */
+int rthip_read_tri_order(rthip_ctx* ctx, uint32_t* out, uint64_t n_tris);
+/* The device triangle records (48 bytes each: p0.xyz,0, e1.xyz,0, e2.xyz,0). */
+int rthip_read_tris_device_layout(rthip_ctx* ctx, void* out, uint64_t n_tris);
+
+/* The render pass of frame() (main.rs:395-401; fs_main, shader.wgsl:994-1012): mean, PBR
+ * Neutral tonemap, then the linear->sRGB transfer the reference gets from its sRGB surface
+ * (main.rs:116) when apply_srgb_oetf != 0, rounded to 8 bits; alpha = 255. */
+int rthip_resolve(rthip_ctx* ctx, uint8_t* rgba8, uint64_t n_pixels, int apply_srgb_oetf);
+
+int rthip_get_counters(rthip_ctx* ctx, rthip_counters* out);
+int rthip_reset_counters(rthip_ctx* ctx);
+int rthip_get_timing(rthip_ctx* ctx, rthip_timing* out);
+int rthip_reset_timing(rthip_ctx* ctx);
+
+int rthip_synchronize(rthip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

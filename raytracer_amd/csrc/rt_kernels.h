@@ -1,0 +1,559 @@
+// The four stages of the path-tracing hot path as HIP kernels for gfx950 (wave64):
+//   generate  camera rays            (shader.wgsl:895-897, 741-779)
+//   extend    closest-hit traversal  (shader.wgsl:598-627, 442-525, 339-438)
+//   shade     miss / kill / BRDF     (shader.wgsl:898-914, 803-885, 941-951)
+//   resolve   mean + tonemap + sRGB  (shader.wgsl:969-1012; main.rs:116)
+// One launch of extend + shade per bounce; paths that survive a bounce are compacted into the
+// next queue with a ballot + prefix count and one atomic per wave.
+#pragma once
+
+#include "rt_device.h"
+
+#define RT_PI 3.141592654f  // shader.wgsl:11
+
+// ------------------------------------------------------------------ intersection primitives
+
+// intersect_aabb, shader.wgsl:415-438.  q0 = (min.xyz, max.x), q1 = (max.y, max.z, .., ..)
+__device__ __forceinline__ float hit_aabb(f3 o, f3 idir, float4 q0, float4 q1) {
+    const f3 bmin = F3(q0.x, q0.y, q0.z), bmax = F3(q0.w, q1.x, q1.y);
+    if (o.x >= bmin.x && o.y >= bmin.y && o.z >= bmin.z && o.x < bmax.x && o.y < bmax.y && o.z < bmax.z)
+        return 0.0f;
+    const f3 rmin = (bmin - o) * idir;
+    const f3 rmax = (bmax - o) * idir;
+    const float t0 = fmaxf(fminf(rmin.x, rmax.x), fmaxf(fminf(rmin.y, rmax.y), fminf(rmin.z, rmax.z)));
+    const float t1 = fminf(fmaxf(rmin.x, rmax.x), fminf(fmaxf(rmin.y, rmax.y), fmaxf(rmin.z, rmax.z)));
+    if (t0 > t1 || t0 < 0.0f) return -1.0f;
+    return t0;
+}
+
+// intersect, shader.wgsl:339-364, on a (p0, e1, e2) record.  Returns t or -1; u, v are the
+// barycentrics intersect_full (shader.wgsl:376-412) would recompute from the same operands.
+__device__ __forceinline__ float hit_tri(f3 o, f3 d, f3 p0, f3 e1, f3 e2, float& u, float& v) {
+    const f3 h = cross(d, e2);
+    const float a = dot(e1, h);
+    if (a > -0.000002f && a < 0.000002f) return -1.0f;
+    const float f = 1.0f / a;
+    const f3 s = o - p0;
+    u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const f3 q = cross(s, e1);
+    v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float t = f * dot(e2, q);
+    return t > 0.000002f ? t : -1.0f;
+}
+
+// shader.wgsl:577-595 on the 3x4 part of inv_transform (column-major, rows 0..2)
+__device__ __forceinline__ f3 xform_dir(f3 x, const float* m) {
+    return F3((m[0] * x.x + m[3] * x.y) + m[6] * x.z, (m[1] * x.x + m[4] * x.y) + m[7] * x.z,
+              (m[2] * x.x + m[5] * x.y) + m[8] * x.z);
+}
+__device__ __forceinline__ f3 xform_pos(f3 x, const float* m) {
+    return F3(((m[0] * x.x + m[3] * x.y) + m[6] * x.z) + m[9], ((m[1] * x.x + m[4] * x.y) + m[7] * x.z) + m[10],
+              ((m[2] * x.x + m[5] * x.y) + m[8] * x.z) + m[11]);
+}
+
+// unpack_rgba8 + sample_texture, shader.wgsl:144-160, 175-182.  The flat index follows the
+// reference arithmetic and is clamped to the texel array.
+__device__ __forceinline__ uint32_t fetch_texel(const SceneDev& sc, uint32_t offset, uint32_t size, float tcx, float tcy) {
+    const uint32_t w = size >> 16, h = size & 0xFFFFu;
+    const uint32_t px = f2u(fractf(tcx) * (float)w);
+    const uint32_t py = f2u(fractf(tcy) * (float)h);
+    uint64_t idx = (uint64_t)(uint32_t)(offset + py * w + px);
+    if (idx >= sc.n_texels) idx = sc.n_texels ? sc.n_texels - 1 : 0;
+    return sc.n_texels ? sc.texels[idx] : 0u;
+}
+
+// ------------------------------------------------------------------ generate
+
+struct GenArgs {
+    PathQueue out;
+    uint32_t* count_out;
+    float     origin[3];
+    float     forward[3];
+    float     right[3];
+    float     up[3];
+    float     fov_factor, aspect, focus, aperture_radius;
+    uint32_t  res_x, res_y, tiles_x, n_tiles;
+    uint32_t  frame;
+    uint32_t  pad;
+    unsigned long long* counters; // may be null
+};
+
+// One lane per pixel, one wave per 8x8 pixel tile (the reference's workgroup shape,
+// shader.wgsl:887), so a wave's camera rays are spatially coherent.
+__global__ __launch_bounds__(256) void k_generate(GenArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = gid >> 6, l = gid & 63u;
+    const uint32_t px = (tile % a.tiles_x) * 8u + (l & 7u);
+    const uint32_t py = (tile / a.tiles_x) * 8u + (l >> 3);
+    const bool valid = tile < a.n_tiles && px < a.res_x && py < a.res_y;
+
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+    if (valid) {
+        uint32_t seed = hash21(hash21(px, py), a.frame); // shader.wgsl:895
+        // camera_ray, shader.wgsl:741-779 (basis vectors and fov factor are per-frame constants)
+        const f3 origin0 = F3(a.origin[0], a.origin[1], a.origin[2]);
+        const f3 forward = F3(a.forward[0], a.forward[1], a.forward[2]);
+        const f3 right = F3(a.right[0], a.right[1], a.right[2]);
+        const f3 up = F3(a.up[0], a.up[1], a.up[2]);
+        f3 pixel_pos = origin0 + forward;
+        const float rx = rnd(seed);
+        const float ry = rnd(seed);
+        const float aax = (float)px + rx, aay = (float)py + ry;
+        const float resx = (float)a.res_x, resy = (float)a.res_y;
+        pixel_pos = pixel_pos + ((right * (aax / resx - 0.5f)) * a.fov_factor) * a.aspect;
+        pixel_pos = pixel_pos + (up * (0.5f - aay / resy)) * a.fov_factor;
+        f3 dir = normalize(pixel_pos - origin0);
+        const float theta = rnd(seed) * 2.0f * RT_PI; // rand_disk, shader.wgsl:669-673
+        const float radius = sqrtf(rnd(seed));
+        const float ax = a.aperture_radius * (radius * cosf(theta));
+        const float ay = a.aperture_radius * (radius * sinf(theta));
+        f3 origin = origin0 + right * ax;
+        origin = origin + up * ay;
+        pixel_pos = pixel_pos + dir * (a.focus - 1.0f);
+        dir = normalize(pixel_pos - origin);
+        s0 = make_float4(origin.x, origin.y, origin.z, dir.x);
+        s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(px + a.res_x * py));
+    }
+    const uint32_t slot = wave_append(valid, a.count_out);
+    if (valid) {
+        a.out.s0[slot] = s0;
+        a.out.s1[slot] = s1;
+        a.out.s2[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        a.out.s3[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (a.counters) {
+        const unsigned long long n = wave_sum(valid ? 1ull : 0ull);
+        if (lane_id() == 0 && n) atomicAdd(&a.counters[C_PATHS], n);
+    }
+}
+
+// ------------------------------------------------------------------ extend
+
+struct ExtArgs {
+    SceneDev  sc;
+    PathQueue in;
+    float4*   hits;
+    const uint32_t* count_in;
+    uint32_t* cursor;
+    uint32_t  stack_depth;
+    uint32_t  tap;            // 1: record primary hits per pixel
+    int32_t*  tap_tri;
+    int32_t*  tap_prim;
+    float*    tap_t;
+    unsigned long long* counters;
+};
+
+// trace_bvh, shader.wgsl:442-525.  The traversal stack lives in LDS, one dword column per lane
+// (stack[level][lane]: conflict-free).  A popped entry is a node index whose (first, count)
+// words are re-read; the reference does not re-test the box of a popped node either.
+template <bool COUNT, int CAP>
+__device__ __forceinline__ int32_t trace_bvh(const SceneDev& sc, f3 o, f3 d, f3 idir, uint32_t root, float& t_max,
+                                             const PrimX& px, uint32_t& seed, uint32_t depth, uint32_t* stack,
+                                             bool& overflow, unsigned long long* cnt) {
+    const float4 r0 = sc.nodes[2 * (size_t)root], r1 = sc.nodes[2 * (size_t)root + 1];
+    if (COUNT) cnt[C_PRIMS]++;
+    if (hit_aabb(o, idir, r0, r1) < -0.5f) return -1;
+    uint32_t cur_first = __float_as_uint(r1.z), cur_count = __float_as_uint(r1.w);
+    float best_t = t_max;
+    int32_t best_i = -1;
+    uint32_t sp = 0;
+    const uint32_t mode = px.alpha_settings & 3u;
+    for (;;) {
+        if (cur_count > 0) {
+            if (COUNT) cnt[C_LEAF]++;
+            for (uint32_t i = cur_first; i < cur_first + cur_count; i++) {
+                const float4 a0 = sc.tris[3 * (size_t)i], a1 = sc.tris[3 * (size_t)i + 1], a2 = sc.tris[3 * (size_t)i + 2];
+                if (COUNT) cnt[C_TRI]++;
+                float u, v;
+                const float t = hit_tri(o, d, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
+                if (t >= 0.0f && t < best_t) {
+                    if (mode != 0u) { // shader.wgsl:464-487
+                        if (COUNT) cnt[C_ALPHA]++;
+                        const float b0 = (1.0f - u) - v;
+                        const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
+                        const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)i);
+                        const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
+                        float tcx = 0.0f, tcy = 0.0f;
+                        tcx += b0 * t0.x; tcy += b0 * t0.y;
+                        tcx += u * t1.x;  tcy += u * t1.y;
+                        tcx += v * t2.x;  tcy += v * t2.y;
+                        float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
+                        if (px.albedo_size != 0u) {
+                            if (COUNT) cnt[C_TEXEL]++;
+                            alpha = (float)(fetch_texel(sc, px.albedo_offset, px.albedo_size, tcx, tcy) & 255u) / 255.0f;
+                        }
+                        if (mode == 1u) {
+                            if (alpha < (float)(px.alpha_settings >> 16) / 65536.0f) continue;
+                        } else {
+                            if (rnd(seed) > alpha) continue;
+                        }
+                    }
+                    best_i = (int32_t)i;
+                    best_t = t;
+                }
+            }
+            if (sp == 0) break;
+            const uint32_t n = stack[(--sp) * RT_WAVE];
+            const float4 q = sc.nodes[2 * (size_t)n + 1];
+            cur_first = __float_as_uint(q.z);
+            cur_count = __float_as_uint(q.w);
+        } else {
+            if (COUNT) cnt[C_INNER]++;
+            const float4* pair = sc.nodes + 2 * (size_t)cur_first; // siblings: one aligned 64-byte fetch
+            const float4 l0 = pair[0], l1 = pair[1], q0 = pair[2], q1 = pair[3];
+            const float left = hit_aabb(o, idir, l0, l1);
+            const float right = hit_aabb(o, idir, q0, q1);
+            const bool lmiss = (left < -0.5f || left > best_t);
+            const bool rmiss = (right < -0.5f || right > best_t);
+            if (lmiss && rmiss) {
+                if (sp == 0) break;
+                const uint32_t n = stack[(--sp) * RT_WAVE];
+                const float4 q = sc.nodes[2 * (size_t)n + 1];
+                cur_first = __float_as_uint(q.z);
+                cur_count = __float_as_uint(q.w);
+            } else {
+                bool go_left;
+                if (lmiss) go_left = false;
+                else if (rmiss) go_left = true;
+                else {
+                    go_left = left < right;
+                    const uint32_t far_child = go_left ? cur_first + 1u : cur_first;
+                    if (sp < depth) { stack[sp * RT_WAVE] = far_child; sp++; }
+                    else { overflow = true; if (COUNT) cnt[C_OVERFLOW]++; } // shader.wgsl:306-313
+                }
+                const float4 c = go_left ? l1 : q1;
+                cur_first = __float_as_uint(c.z);
+                cur_count = __float_as_uint(c.w);
+            }
+        }
+    }
+    t_max = best_t;
+    return best_i;
+}
+
+// Conservative slab overlap of a world-space ray with a padded world-space box: a ray that
+// fails it cannot touch anything inside the primitive, so the primitive is skipped before its
+// ray transform.  Primitives that pass go through the reference's exact local-space root test.
+__device__ __forceinline__ bool overlaps_world_box(f3 o, f3 idir, const float* b) {
+    const float ax = (b[0] - o.x) * idir.x, bx = (b[3] - o.x) * idir.x;
+    const float ay = (b[1] - o.y) * idir.y, by = (b[4] - o.y) * idir.y;
+    const float az = (b[2] - o.z) * idir.z, bz = (b[5] - o.z) * idir.z;
+    const float t0 = fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float t1 = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    return !(t0 > t1 || t1 < 0.0f);
+}
+
+// Persistent waves: each wave pulls 64 consecutive queue slots at a time from a global cursor
+// until the queue is drained.  trace(), shader.wgsl:598-627.
+template <bool COUNT, int CAP>
+__global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
+    __shared__ uint32_t lds_stack[4 * CAP * RT_WAVE];
+    const uint32_t lane = lane_id();
+    uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (CAP * RT_WAVE) + lane;
+    const uint32_t n = *a.count_in;
+    const uint32_t depth = a.stack_depth < (uint32_t)CAP ? a.stack_depth : (uint32_t)CAP;
+    unsigned long long cnt[12];
+    if (COUNT) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) cnt[k] = 0;
+    }
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.cursor, RT_WAVE);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t slot = base + lane;
+        if (slot < n) {
+            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+            const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
+            const f3 idir = rcp3(d);
+            uint32_t seed = __float_as_uint(s1.z);
+            int32_t closest_idx = -1;
+            float closest_t = 99999999.0f;
+            uint32_t closest_prim = 0;
+            bool overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
+            if (COUNT) cnt[C_RAYS]++;
+            for (uint32_t p = 0; p < a.sc.n_prims; p++) {
+                const PrimX& px = a.sc.primx[p];
+                if (!overlaps_world_box(o, idir, px.wbox)) continue;
+                const f3 td = xform_dir(d, px.inv);
+                const float scale = length(td);
+                const f3 ld = td / scale;
+                const f3 lo = xform_pos(o, px.inv);
+                const f3 lidir = rcp3(ld);
+                float new_t = closest_t * scale;
+                const int32_t idx = trace_bvh<COUNT, CAP>(a.sc, lo, ld, lidir, px.root, new_t, px, seed, depth, stack,
+                                                          overflow, cnt);
+                if (idx >= 0) {
+                    closest_t = new_t / scale;
+                    closest_idx = idx;
+                    closest_prim = p;
+                }
+            }
+            a.hits[slot] = make_float4(closest_t, __int_as_float(closest_idx),
+                                       __uint_as_float(closest_prim | (overflow ? 0x80000000u : 0u)),
+                                       __uint_as_float(seed));
+            if (a.tap) {
+                const uint32_t pix = __float_as_uint(s1.w);
+                a.tap_tri[pix] = closest_idx;
+                a.tap_prim[pix] = closest_idx >= 0 ? (int32_t)closest_prim : -1;
+                a.tap_t[pix] = closest_t;
+            }
+        }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned long long s = wave_sum(cnt[k]);
+            if (lane == 0 && s) atomicAdd(&a.counters[k], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shade
+
+struct ShadeArgs {
+    SceneDev  sc;
+    PathQueue in;
+    PathQueue out;
+    const float4* hits;
+    const uint32_t* count_in;
+    uint32_t* count_out;
+    float4*   accum;
+    uint32_t* tap_seed;     // null unless taps are on for this frame
+    float     term_prob;
+    uint32_t  last_bounce;  // 1: survivors of this bounce end here (loop bound, shader.wgsl:898)
+    uint32_t  overwrite;    // reject_hist == 1 (shader.wgsl:947-951)
+    uint32_t  pad;
+    unsigned long long* counters;
+};
+
+// unpack_vec3_octrahedral, shader.wgsl:185-197
+__device__ __forceinline__ f3 unpack_oct(float fx_in, float fy_in) {
+    const float fx = fx_in * 2.0f - 1.0f, fy = fy_in * 2.0f - 1.0f;
+    f3 n = F3(fx, fy, 1.0f - fabsf(fx) - fabsf(fy));
+    const float t = fminf(fmaxf(-n.z, 0.0f), 1.0f);
+    n.x -= t * sign11(n.x);
+    n.y -= t * sign11(n.y);
+    return normalize(n);
+}
+
+// rand_sphere, shader.wgsl:662-667
+__device__ __forceinline__ f3 rand_sphere(uint32_t& seed) {
+    const float theta = rnd(seed) * 2.0f * RT_PI;
+    const float z = rnd(seed) * 2.0f - 1.0f;
+    const float radius = sqrtf(1.0f - z * z);
+    return F3(radius * cosf(theta), radius * sinf(theta), z);
+}
+
+__device__ __forceinline__ f3 unpack_rgb(uint32_t x) { // shader.wgsl:175-182
+    return F3((float)((x >> 24) & 255u) / 255.0f, (float)((x >> 16) & 255u) / 255.0f, (float)((x >> 8) & 255u) / 255.0f);
+}
+__device__ __forceinline__ f3 to_linear(f3 c) { // shader.wgsl:725-728
+    return F3(powf(c.x, 2.2f), powf(c.y, 2.2f), powf(c.z, 2.2f));
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    const uint32_t n = *a.count_in;
+    const uint32_t n_pad = (n + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned long long c_shade = 0, c_miss = 0, c_kill = 0, c_texel = 0;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_pad; slot += stride) {
+        bool survive = false;
+        float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
+        if (slot < n) {
+            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
+            const float4 h = a.hits[slot];
+            f3 origin = F3(s0.x, s0.y, s0.z), dir = F3(s0.w, s1.x, s1.y);
+            f3 thr = F3(s2.x, s2.y, s2.z), lit = F3(s3.x, s3.y, s3.z);
+            const uint32_t pix = __float_as_uint(s1.w);
+            uint32_t seed = __float_as_uint(h.w);
+            const int32_t tri = __float_as_int(h.y);
+            const uint32_t primw = __float_as_uint(h.z);
+            const bool overflow = (primw >> 31) != 0u;
+            const uint32_t prim = primw & 0x7FFFFFFFu;
+            const float hit_t = h.x;
+
+            if (tri < 0) { // handle_miss / sky / sample_env_map, shader.wgsl:883-885, 691-702
+                if (COUNT) c_miss++;
+                const float u = atan2f(dir.y, dir.x) / (RT_PI * 2.0f) + 0.5f;
+                const float v = asinf(-dir.z) / RT_PI + 0.5f;
+                uint32_t ex = f2u(u * (float)a.sc.env_w), ey = f2u(v * (float)a.sc.env_h);
+                if (ex >= a.sc.env_w) ex = a.sc.env_w - 1u;
+                if (ey >= a.sc.env_h) ey = a.sc.env_h - 1u;
+                const float4 e = a.sc.env[(size_t)ey * a.sc.env_w + ex];
+                lit = lit + thr * F3(e.x * 1.0f, e.y * 1.0f, e.z * 1.0f);
+            } else if (rnd(seed) < a.term_prob) { // shader.wgsl:907-909
+                if (COUNT) c_kill++;
+                thr = thr / a.term_prob;
+            } else {
+                thr = thr / (1.0f - a.term_prob);
+                // ---- handle_surface_hit_brdf, shader.wgsl:803-881
+                if (COUNT) c_shade++;
+                const PrimitiveD& pr = a.sc.prims[prim];
+                const float* im = pr.inv_transform;
+                // the primitive-space ray and the geometric normal, as trace() recomputes them
+                // for the winning triangle (shader.wgsl:617-625, 376-412)
+                const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
+                                 (im[2] * dir.x + im[6] * dir.y) + im[10] * dir.z);
+                const f3 ld = normalize(td);
+                const f3 lo = F3(((im[0] * origin.x + im[4] * origin.y) + im[8] * origin.z) + im[12],
+                                 ((im[1] * origin.x + im[5] * origin.y) + im[9] * origin.z) + im[13],
+                                 ((im[2] * origin.x + im[6] * origin.y) + im[10] * origin.z) + im[14]);
+                const float4 a0 = a.sc.tris[3 * (size_t)tri], a1 = a.sc.tris[3 * (size_t)tri + 1], a2 = a.sc.tris[3 * (size_t)tri + 2];
+                const f3 p0 = F3(a0.x, a0.y, a0.z), e1 = F3(a1.x, a1.y, a1.z), e2 = F3(a2.x, a2.y, a2.z);
+                f3 ng = normalize(cross(e1, e2));
+                ng = ng * (-sign11(dot(ng, ld)));
+                float bu = 0.333f, bv = 0.333f, b0 = 0.333f;
+                {
+                    float u, v;
+                    const float t = hit_tri(lo, ld, p0, e1, e2, u, v);
+                    if (t >= 0.0f) { b0 = (1.0f - u) - v; bu = u; bv = v; }
+                }
+                // transform_normal, shader.wgsl:585-587
+                const f3 n_geo = normalize(F3((im[0] * ng.x + im[1] * ng.y) + im[2] * ng.z, (im[4] * ng.x + im[5] * ng.y) + im[6] * ng.z,
+                                              (im[8] * ng.x + im[9] * ng.y) + im[10] * ng.z));
+                (void)rnd(seed); // shader.wgsl:804
+                origin = origin + dir * hit_t;
+                origin = origin + n_geo * 0.001f;
+
+                // tri_ext_interpolate, shader.wgsl:229-253
+                const float4* ex = a.sc.exts + 6 * (size_t)tri;
+                const float4 v0a = ex[0], v0b = ex[1], v1a = ex[2], v1b = ex[3], v2a = ex[4], v2b = ex[5];
+                float tc0x = 0.0f, tc0y = 0.0f, tc1x = 0.0f, tc1y = 0.0f;
+                tc0x += b0 * v0a.x; tc0y += b0 * v0a.y; tc1x += b0 * v0a.z; tc1y += b0 * v0a.w;
+                f3 sn = F3(0.0f, 0.0f, 0.0f) + unpack_oct(v0b.x, v0b.y) * b0;
+                tc0x += bu * v1a.x; tc0y += bu * v1a.y; tc1x += bu * v1a.z; tc1y += bu * v1a.w;
+                sn = sn + unpack_oct(v1b.x, v1b.y) * bu;
+                tc0x += bv * v2a.x; tc0y += bv * v2a.y; tc1x += bv * v2a.z; tc1y += bv * v2a.w;
+                sn = sn + unpack_oct(v2b.x, v2b.y) * bv;
+                sn = normalize(sn);
+                if (length(sn) > 0.001f) { // shader.wgsl:816-824
+                    const f3 nn = normalize(sn);
+                    sn = normalize(F3((im[0] * nn.x + im[1] * nn.y) + im[2] * nn.z, (im[4] * nn.x + im[5] * nn.y) + im[6] * nn.z,
+                                      (im[8] * nn.x + im[9] * nn.y) + im[10] * nn.z));
+                    if (dot(sn, n_geo) < 0.0f) sn = neg(sn);
+                } else {
+                    sn = n_geo;
+                }
+
+                const MaterialD& m = pr.material;
+                f3 albedo = F3(m.albedo_factor[0], m.albedo_factor[1], m.albedo_factor[2]);
+                if (m.albedo.size != 0u) {
+                    const bool s1set = m.albedo_texcoord >= 1u;
+                    if (COUNT) c_texel++;
+                    albedo = albedo * to_linear(unpack_rgb(fetch_texel(a.sc, m.albedo.offset, m.albedo.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y)));
+                } else {
+                    albedo = albedo * F3(0.01f, 0.02f, 0.03f);
+                }
+                f3 emissive = F3(m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2]);
+                if (m.emissive.size != 0u) {
+                    const bool s1set = m.emissive_texcoord >= 1u;
+                    if (COUNT) c_texel++;
+                    emissive = emissive * to_linear(unpack_rgb(fetch_texel(a.sc, m.emissive.offset, m.emissive.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y)));
+                }
+                float metallic_chance = m.metallic_factor;
+                float roughness = m.roughness_factor;
+                if (m.metallic_roughness.size != 0u) {
+                    const bool s1set = m.metal_r_texcoord >= 1u;
+                    if (COUNT) c_texel++;
+                    const f3 mr = unpack_rgb(fetch_texel(a.sc, m.metallic_roughness.offset, m.metallic_roughness.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+                    metallic_chance = mr.z;
+                    roughness *= mr.y;
+                }
+
+                const bool metal = rnd(seed) < metallic_chance;
+                const float f0x = metal ? albedo.x : 0.04f;
+                f3 hemi = rand_sphere(seed); // rand_hemisphere, shader.wgsl:675-681
+                if (dot(hemi, sn) < 0.0f) hemi = hemi * -1.0f;
+                const float mt = roughness * roughness * 0.8f;
+                const f3 mn = normalize(F3(mixf(sn.x, hemi.x, mt), mixf(sn.y, hemi.y, mt), mixf(sn.z, hemi.z, mt)));
+                const float pw = powf(1.0f - dot(mn, neg(dir)), 5.0f); // fresnel_schlick, shader.wgsl:791-793
+                const float fresnel_x = f0x + (1.0f - f0x) * pw;
+                const bool specular = rnd(seed) < fresnel_x;
+
+                lit = lit + emissive * thr;
+                if (!specular || metal) thr = thr * albedo;
+                if (specular || metal) {
+                    f3 nd = dir - mn * (2.0f * dot(mn, dir)); // reflect
+                    if (dot(nd, sn) < 0.0f) nd = normalize(nd - sn * dot(nd, sn)); // project_to_hemisphere
+                    dir = nd;
+                } else {
+                    dir = normalize(sn + rand_sphere(seed)); // sample_lambert, shader.wgsl:781-785
+                }
+                survive = !a.last_bounce;
+                o0 = make_float4(origin.x, origin.y, origin.z, dir.x);
+                o1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(pix));
+                o2 = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                o3 = make_float4(lit.x, lit.y, lit.z, 0.0f);
+            }
+
+            if (!survive) { // the path ends: shader.wgsl:941-951
+                if (overflow) lit = F3(1.0f, 1.0f, 0.0f);
+                if (a.overwrite) {
+                    a.accum[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
+                } else {
+                    const float4 p = a.accum[pix];
+                    a.accum[pix] = make_float4(p.x + lit.x, p.y + lit.y, p.z + lit.z, p.w + 1.0f);
+                }
+                if (a.tap_seed) a.tap_seed[pix] = seed;
+            }
+        }
+        const uint32_t dst = wave_append(survive, a.count_out);
+        if (survive) {
+            a.out.s0[dst] = o0;
+            a.out.s1[dst] = o1;
+            a.out.s2[dst] = o2;
+            a.out.s3[dst] = o3;
+        }
+    }
+    if (COUNT) {
+        const unsigned long long s0 = wave_sum(c_shade), s1 = wave_sum(c_miss), s2 = wave_sum(c_kill), s3 = wave_sum(c_texel);
+        if (lane_id() == 0) {
+            if (s0) atomicAdd(&a.counters[C_SHADE], s0);
+            if (s1) atomicAdd(&a.counters[C_MISS], s1);
+            if (s2) atomicAdd(&a.counters[C_KILL], s2);
+            if (s3) atomicAdd(&a.counters[C_TEXEL], s3);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ resolve
+
+// tonemap_pbr_neutral, shader.wgsl:969-992
+__device__ __forceinline__ f3 tonemap_pbr_neutral(f3 c) {
+    const float start_compression = 0.76f; // 0.8 - 0.04
+    const float desaturation = 0.15f;
+    const float x = fminf(c.x, fminf(c.y, c.z));
+    float offset = 0.04f;
+    if (x < 0.08f) offset = x - 6.25f * x * x;
+    c = F3(c.x - offset, c.y - offset, c.z - offset);
+    const float peak = fmaxf(c.x, fmaxf(c.y, c.z));
+    if (peak < start_compression) return c;
+    const float d = 1.0f - start_compression;
+    const float new_peak = 1.0f - d * d / (peak + d - start_compression);
+    c = c * (new_peak / peak);
+    const float g = 1.0f - 1.0f / (desaturation * (peak - new_peak) + 1.0f);
+    return F3(mixf(c.x, new_peak * 1.0f, g), mixf(c.y, new_peak * 1.0f, g), mixf(c.z, new_peak * 1.0f, g));
+}
+
+__device__ __forceinline__ uint32_t to_unorm8(float c, bool srgb) {
+    if (!(c > 0.0f)) c = 0.0f;
+    if (c > 1.0f) c = 1.0f;
+    if (srgb) c = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    return (uint32_t)(c * 255.0f + 0.5f);
+}
+
+// fs_main, shader.wgsl:994-1012, followed by the sRGB render target's encode (main.rs:116).
+// Output bytes r, g, b, a per pixel (little-endian packed word).
+__global__ __launch_bounds__(256) void k_resolve(const float4* accum, uint32_t* rgba8, uint64_t n, int srgb) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 s = accum[i];
+        const f3 col = tonemap_pbr_neutral(F3(s.x / s.w * 1.0f, s.y / s.w * 1.0f, s.z / s.w * 1.0f));
+        rgba8[i] = to_unorm8(col.x, srgb != 0) | (to_unorm8(col.y, srgb != 0) << 8) | (to_unorm8(col.z, srgb != 0) << 16) | 0xFF000000u;
+    }
+}

@@ -1,0 +1,776 @@
+// C ABI of the MI355X path-tracing hot path (include/rthip.h): context, scene upload and
+// repack, per-frame stage launches, read-back.  gfx950 only; compile with -ffp-contract=off.
+
+#include "../../include/rthip.h"
+#include "rt_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_global_error;
+
+struct EventPair {
+    int        stage;
+    hipEvent_t e0, e1;
+};
+
+} // namespace
+
+struct rthip_ctx {
+    int         device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int         n_cu = 0;
+    std::string error;
+
+    // scene
+    bool      have_scene = false;
+    SceneDev  sc{};
+    void*     d_nodes = nullptr;
+    void*     d_tris = nullptr;
+    void*     d_exts = nullptr;
+    void*     d_primx = nullptr;
+    void*     d_prims = nullptr;
+    void*     d_texels = nullptr;
+    void*     d_env = nullptr;
+    uint64_t  n_tris = 0, n_nodes = 0, n_dev_nodes = 0;
+    std::vector<uint32_t> node_index_map;
+
+    // frame state
+    bool      have_uniforms = false;
+    uint8_t   uniforms[608];
+    uint32_t  res_x = 0, res_y = 0;
+    uint32_t  reject_hist = 1;
+    uint64_t  n_pixels = 0;
+
+    // per-resolution buffers
+    float4*   accum_own = nullptr;
+    float4*   accum = nullptr;       // own or bound
+    uint64_t  accum_bound_pixels = 0;
+    bool      accum_is_bound = false;
+    float4*   queue_mem = nullptr;   // 2 queues x 4 streams x n_pixels
+    float4*   hits = nullptr;
+    uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors
+    int32_t*  tap_tri = nullptr;
+    int32_t*  tap_prim = nullptr;
+    float*    tap_t = nullptr;
+    uint32_t* tap_seed = nullptr;
+    bool      taps_valid = false;
+    uint64_t  buf_pixels = 0;
+
+    unsigned long long* d_counters = nullptr;
+
+    std::vector<EventPair>  pending_events;
+    std::vector<hipEvent_t> free_events;
+    rthip_timing            timing{};
+};
+
+namespace {
+
+int fail(rthip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_global_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, RTHIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void free_dev(void*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+template <typename T> void free_dev_t(T*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void free_scene(rthip_ctx* c) {
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx);
+    free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
+    c->have_scene = false;
+}
+
+void free_frame_buffers(rthip_ctx* c) {
+    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits);
+    free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
+    c->buf_pixels = 0;
+    if (!c->accum_is_bound) c->accum = nullptr;
+}
+
+// double-precision 4x4 inverse (column-major); false when singular or non-finite
+bool invert4(const double m[16], double out[16]) {
+    double inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    for (int i = 0; i < 16; i++) {
+        out[i] = inv[i] / det;
+        if (!std::isfinite(out[i])) return false;
+    }
+    return true;
+}
+
+struct HostNode { float aabb[6]; uint32_t first, count; };
+struct HostTri { float v[3][4]; };
+
+int ensure_frame_buffers(rthip_ctx* c) {
+    const uint64_t n = c->n_pixels;
+    if (c->buf_pixels == n && c->queue_mem) return RTHIP_OK;
+    free_frame_buffers(c);
+    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * n));
+    HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * n));
+    HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
+    HIP_TRY(c, hipMalloc((void**)&c->tap_prim, sizeof(int32_t) * n));
+    HIP_TRY(c, hipMalloc((void**)&c->tap_t, sizeof(float) * n));
+    HIP_TRY(c, hipMalloc((void**)&c->tap_seed, sizeof(uint32_t) * n));
+    c->taps_valid = false;
+    if (!c->accum_is_bound) {
+        HIP_TRY(c, hipMalloc((void**)&c->accum_own, sizeof(float4) * n));
+        HIP_TRY(c, hipMemsetAsync(c->accum_own, 0, sizeof(float4) * n, c->stream));
+        c->accum = c->accum_own;
+    }
+    c->buf_pixels = n;
+    return RTHIP_OK;
+}
+
+hipEvent_t get_event(rthip_ctx* c) {
+    if (!c->free_events.empty()) {
+        hipEvent_t e = c->free_events.back();
+        c->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageTimer {
+    rthip_ctx* c;
+    bool       on;
+    EventPair  p{};
+    StageTimer(rthip_ctx* ctx, bool enabled, int stage) : c(ctx), on(enabled) {
+        if (!on) return;
+        p.stage = stage;
+        p.e0 = get_event(c);
+        p.e1 = get_event(c);
+        (void)hipEventRecord(p.e0, c->stream);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(p.e1, c->stream);
+        c->pending_events.push_back(p);
+    }
+};
+
+int drain_events(rthip_ctx* c) {
+    if (c->pending_events.empty()) return RTHIP_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (const EventPair& p : c->pending_events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            c->timing.ms[p.stage] += (double)ms;
+            c->timing.launches[p.stage] += 1;
+        }
+        c->free_events.push_back(p.e0);
+        c->free_events.push_back(p.e1);
+    }
+    c->pending_events.clear();
+    return RTHIP_OK;
+}
+
+template <typename K> int occupancy_blocks(K kernel, int block) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 2;
+    return nb;
+}
+
+} // namespace
+
+extern "C" {
+
+int rthip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* rthip_last_error(const rthip_ctx* ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
+
+int rthip_create(int device_ordinal, rthip_ctx** out) {
+    if (!out) return fail(nullptr, RTHIP_ERR_INVALID, "rthip_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, RTHIP_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, RTHIP_ERR_NO_DEVICE, "device ordinal %d out of range (0..%d)", device_ordinal, n - 1);
+    DeviceGuard g(device_ordinal);
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RTHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_ordinal, prop.gcnArchName);
+    rthip_ctx* c = new rthip_ctx();
+    c->device = device_ordinal;
+    c->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(nullptr, RTHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    e = hipMalloc((void**)&c->ctrl, sizeof(uint32_t) * 128);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(Counters));
+    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(Counters));
+    if (e != hipSuccess) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    *out = c;
+    return RTHIP_OK;
+}
+
+void rthip_destroy(rthip_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending_events) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto& e : c->free_events) (void)hipEventDestroy(e);
+    free_scene(c);
+    free_frame_buffers(c);
+    free_dev_t(c->ctrl);
+    free_dev_t(c->d_counters);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rthip_set_stream(rthip_ctx* c, void* hip_stream) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RTHIP_OK;
+}
+
+int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!s) return fail(c, RTHIP_ERR_INVALID, "upload_scene: null scene");
+    if (!s->prims || s->n_prims == 0) return fail(c, RTHIP_ERR_INVALID, "upload_scene: no primitives");
+    if (!s->nodes || s->n_nodes == 0) return fail(c, RTHIP_ERR_INVALID, "upload_scene: no BVH nodes");
+    if (s->n_tris && (!s->tris || !s->tri_exts)) return fail(c, RTHIP_ERR_INVALID, "upload_scene: null triangle arrays");
+    if (!s->env || s->env_w == 0 || s->env_h == 0) return fail(c, RTHIP_ERR_INVALID, "upload_scene: no environment map");
+    if (s->n_texels && !s->texels) return fail(c, RTHIP_ERR_INVALID, "upload_scene: null texel array");
+    if (s->n_nodes >= 0x7FFFFFFFull || s->n_tris >= 0x7FFFFFFFull || s->n_prims >= 0x7FFFFFFFu)
+        return fail(c, RTHIP_ERR_INVALID, "upload_scene: more than 2^31-1 nodes, triangles or primitives");
+
+    const HostNode*   nodes = static_cast<const HostNode*>(s->nodes);
+    const HostTri*    tris = static_cast<const HostTri*>(s->tris);
+    const PrimitiveD* prims = static_cast<const PrimitiveD*>(s->prims);
+
+    // The kernels walk the tree without bounds checks, so the tree is validated here: every
+    // leaf range inside the triangle array, every child pair inside the node array and behind
+    // its parent (which also rules out cycles; the reference builder appends children after
+    // their parent, scene.rs:1041-1046).
+    for (uint64_t i = 0; i < s->n_nodes; i++) {
+        const HostNode& n = nodes[i];
+        if (n.count > 0) {
+            if ((uint64_t)n.first + n.count > s->n_tris)
+                return fail(c, RTHIP_ERR_INVALID, "upload_scene: leaf node %llu covers triangles [%u, %u) of %llu", (unsigned long long)i, n.first, n.first + n.count, (unsigned long long)s->n_tris);
+        } else {
+            if ((uint64_t)n.first + 1 >= s->n_nodes || (uint64_t)n.first <= i)
+                return fail(c, RTHIP_ERR_INVALID, "upload_scene: inner node %llu has children at %u (must lie after it, inside %llu nodes)", (unsigned long long)i, n.first, (unsigned long long)s->n_nodes);
+        }
+    }
+    std::vector<uint32_t> roots;
+    for (uint32_t p = 0; p < s->n_prims; p++) {
+        if (prims[p].bvh_idx >= s->n_nodes) return fail(c, RTHIP_ERR_INVALID, "upload_scene: primitive %u has bvh_idx %u of %llu nodes", p, prims[p].bvh_idx, (unsigned long long)s->n_nodes);
+        roots.push_back(prims[p].bvh_idx);
+    }
+    roots.push_back(0);
+    std::sort(roots.begin(), roots.end());
+    roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+
+    // Device node layout: same records, same tree.  Each BVH (a contiguous run starting at a
+    // primitive's root) is shifted so that its root sits at an odd index; the builder appends
+    // children in pairs after the root, so every sibling pair then starts on a 64-byte line.
+    std::vector<uint32_t> map(s->n_nodes);
+    uint64_t dcur = 0;
+    for (size_t k = 0; k < roots.size(); k++) {
+        const uint64_t seg_begin = roots[k], seg_end = (k + 1 < roots.size()) ? roots[k + 1] : s->n_nodes;
+        if ((dcur & 1ull) == 0) dcur++;
+        for (uint64_t i = seg_begin; i < seg_end; i++) map[i] = (uint32_t)(dcur + (i - seg_begin));
+        dcur += seg_end - seg_begin;
+    }
+    const uint64_t n_dev_nodes = dcur;
+    if (n_dev_nodes >= 0x7FFFFFFFull) return fail(c, RTHIP_ERR_INVALID, "upload_scene: device node array exceeds 2^31-1 records");
+    std::vector<HostNode> dev_nodes(n_dev_nodes);
+    std::memset(dev_nodes.data(), 0, sizeof(HostNode) * n_dev_nodes);
+    for (uint64_t i = 0; i < s->n_nodes; i++) {
+        HostNode n = nodes[i];
+        if (n.count == 0) n.first = map[n.first];
+        dev_nodes[map[i]] = n;
+    }
+    // padding records stay zero; nothing references them
+
+    // Triangles: (p0, e1, e2); the edges are the same f32 subtractions the shader performs per
+    // test (shader.wgsl:340-341), done once.  Order = uploaded order.
+    std::vector<float> dev_tris((size_t)s->n_tris * 12);
+    for (uint64_t i = 0; i < s->n_tris; i++) {
+        const HostTri& t = tris[i];
+        float* o = &dev_tris[(size_t)i * 12];
+        for (int k = 0; k < 3; k++) {
+            o[k] = t.v[0][k];
+            o[4 + k] = t.v[1][k] - t.v[0][k];
+            o[8 + k] = t.v[2][k] - t.v[0][k];
+        }
+        o[3] = o[7] = o[11] = 0.0f;
+    }
+
+    std::vector<PrimX> primx(s->n_prims);
+    for (uint32_t p = 0; p < s->n_prims; p++) {
+        const PrimitiveD& pr = prims[p];
+        PrimX& x = primx[p];
+        std::memset(&x, 0, sizeof x);
+        for (int col = 0; col < 4; col++)
+            for (int row = 0; row < 3; row++) x.inv[col * 3 + row] = pr.inv_transform[col * 4 + row];
+        x.root = map[pr.bvh_idx];
+        x.alpha_settings = pr.material.alpha_settings;
+        x.albedo_offset = pr.material.albedo.offset;
+        x.albedo_size = pr.material.albedo.size;
+        x.albedo_texcoord = pr.material.albedo_texcoord;
+        // world bound of the root box through the inverse of inv_transform (in double), padded
+        const float inf = std::numeric_limits<float>::infinity();
+        float wb[6] = {-inf, -inf, -inf, inf, inf, inf};
+        double im[16], fw[16];
+        for (int k = 0; k < 16; k++) im[k] = (double)pr.inv_transform[k];
+        const HostNode& root = nodes[pr.bvh_idx];
+        bool finite_box = true;
+        for (int k = 0; k < 6; k++) finite_box = finite_box && std::isfinite(root.aabb[k]);
+        if (finite_box && invert4(im, fw)) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            double mag = 0.0;
+            bool ok = true;
+            for (int corner = 0; corner < 8; corner++) {
+                const double x0 = root.aabb[(corner & 1) ? 3 : 0], y0 = root.aabb[(corner & 2) ? 4 : 1], z0 = root.aabb[(corner & 4) ? 5 : 2];
+                const double w = fw[3] * x0 + fw[7] * y0 + fw[11] * z0 + fw[15];
+                for (int r = 0; r < 3; r++) {
+                    double v = fw[r] * x0 + fw[4 + r] * y0 + fw[8 + r] * z0 + fw[12 + r];
+                    if (!(std::fabs(w - 1.0) < 1e-9)) ok = false; // projective: give up on culling
+                    if (!std::isfinite(v)) ok = false;
+                    lo[r] = std::min(lo[r], v);
+                    hi[r] = std::max(hi[r], v);
+                    mag = std::max(mag, std::fabs(v));
+                }
+            }
+            if (ok) {
+                const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
+                const double pad = 1e-4 * (ext + mag) + 1e-5;
+                for (int r = 0; r < 3; r++) {
+                    wb[r] = (float)(lo[r] - pad);
+                    wb[3 + r] = (float)(hi[r] + pad);
+                    wb[r] = std::nextafter(wb[r], -inf);
+                    wb[3 + r] = std::nextafter(wb[3 + r], inf);
+                }
+            }
+        }
+        std::memcpy(x.wbox, wb, sizeof wb);
+    }
+
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    auto upload = [&](void*& dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(&dst, bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIP_TRY(c, upload(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes));
+    HIP_TRY(c, upload(c->d_tris, dev_tris.data(), sizeof(float) * dev_tris.size()));
+    HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
+    HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
+    HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
+    HIP_TRY(c, upload(c->d_texels, s->texels, sizeof(uint32_t) * s->n_texels));
+    HIP_TRY(c, upload(c->d_env, s->env, sizeof(float) * 4 * (size_t)s->env_w * s->env_h));
+
+    c->sc.nodes = static_cast<const float4*>(c->d_nodes);
+    c->sc.tris = static_cast<const float4*>(c->d_tris);
+    c->sc.exts = static_cast<const float4*>(c->d_exts);
+    c->sc.primx = static_cast<const PrimX*>(c->d_primx);
+    c->sc.prims = static_cast<const PrimitiveD*>(c->d_prims);
+    c->sc.texels = static_cast<const uint32_t*>(c->d_texels);
+    c->sc.env = static_cast<const float4*>(c->d_env);
+    c->sc.n_texels = s->n_texels;
+    c->sc.env_w = s->env_w;
+    c->sc.env_h = s->env_h;
+    c->sc.n_prims = s->n_prims;
+    c->n_tris = s->n_tris;
+    c->n_nodes = s->n_nodes;
+    c->n_dev_nodes = n_dev_nodes;
+    c->node_index_map.swap(map);
+    c->have_scene = true;
+    c->reject_hist = 1;
+    return RTHIP_OK;
+}
+
+int rthip_set_frame_uniforms(rthip_ctx* c, const void* blob608) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!blob608) return fail(c, RTHIP_ERR_INVALID, "set_frame_uniforms: null blob");
+    uint32_t res[2], reject;
+    std::memcpy(res, static_cast<const uint8_t*>(blob608) + 576, 8);
+    std::memcpy(&reject, static_cast<const uint8_t*>(blob608) + 592, 4);
+    if (res[0] == 0 || res[1] == 0 || (uint64_t)res[0] * res[1] >= 0x7FFFFFFFull)
+        return fail(c, RTHIP_ERR_INVALID, "set_frame_uniforms: resolution %ux%u is empty or above 2^31-1 pixels", res[0], res[1]);
+    const uint64_t np = (uint64_t)res[0] * res[1];
+    if (c->accum_is_bound && np != c->accum_bound_pixels)
+        return fail(c, RTHIP_ERR_INVALID, "set_frame_uniforms: %ux%u does not match the bound accumulator (%llu pixels)", res[0], res[1], (unsigned long long)c->accum_bound_pixels);
+    std::memcpy(c->uniforms, blob608, 608);
+    const bool resized = (res[0] != c->res_x || res[1] != c->res_y);
+    c->res_x = res[0];
+    c->res_y = res[1];
+    c->n_pixels = np;
+    if (reject == 1 || resized) c->reject_hist = 1;
+    c->have_uniforms = true;
+    return RTHIP_OK;
+}
+
+void rthip_default_params(rthip_render_params* p) {
+    if (!p) return;
+    p->max_bounces = 8;
+    p->term_prob = 0.5f;
+    p->aperture_radius = 0.025f;
+    p->stack_depth = 23;
+    p->enable_sun = 0;
+    p->flags = 0;
+}
+
+int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride, const rthip_render_params* params) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "render: no scene uploaded");
+    if (!c->have_uniforms) return fail(c, RTHIP_ERR_STATE, "render: no frame uniforms set");
+    rthip_render_params P;
+    if (params) P = *params;
+    else rthip_default_params(&P);
+    if (P.max_bounces == 0 || P.max_bounces > 63) return fail(c, RTHIP_ERR_INVALID, "render: max_bounces %u outside 1..63", P.max_bounces);
+    if (!(P.term_prob >= 0.0f && P.term_prob < 1.0f)) return fail(c, RTHIP_ERR_INVALID, "render: term_prob %g outside [0,1)", (double)P.term_prob);
+    if (P.stack_depth == 0 || P.stack_depth > RTHIP_MAX_STACK_DEPTH) return fail(c, RTHIP_ERR_INVALID, "render: stack_depth %u outside 1..%u", P.stack_depth, RTHIP_MAX_STACK_DEPTH);
+    if (P.enable_sun) return fail(c, RTHIP_ERR_UNSUPPORTED, "render: the sun extension is not built into this library");
+    uint32_t prim_count;
+    std::memcpy(&prim_count, c->uniforms + 600, 4);
+    if (prim_count != c->sc.n_prims) return fail(c, RTHIP_ERR_INVALID, "render: uniforms say %u primitives, scene has %u", prim_count, c->sc.n_prims);
+    if (n_frames == 0) return RTHIP_OK;
+
+    DeviceGuard g(c->device);
+    int rc = ensure_frame_buffers(c);
+    if (rc != RTHIP_OK) return rc;
+    if (c->accum_is_bound && c->accum_bound_pixels != c->n_pixels) return fail(c, RTHIP_ERR_STATE, "render: bound accumulator size mismatch");
+
+    const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
+    const bool taps = (P.flags & RTHIP_FLAG_TAPS) != 0;
+    const bool timing = (P.flags & RTHIP_FLAG_TIMING) != 0;
+    const uint64_t np = c->n_pixels;
+
+    // camera constants of camera_ray (shader.wgsl:744-755), identical for every pixel
+    float cam[12];
+    std::memcpy(cam, c->uniforms + 512, 48);
+    GenArgs ga{};
+    const float fwd[3] = {cam[0], cam[1], cam[2]};
+    const float fovy = cam[3];
+    ga.fov_factor = (std::sin(fovy / 2.0f) / std::cos(fovy / 2.0f)) * 2.0f;
+    {
+        // right = normalize(cross(forward, (0,0,1))), up = normalize(cross(right, forward))
+        float r[3] = {fwd[1] * 1.0f - fwd[2] * 0.0f, fwd[2] * 0.0f - fwd[0] * 1.0f, fwd[0] * 0.0f - fwd[1] * 0.0f};
+        float rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        for (int k = 0; k < 3; k++) r[k] = r[k] / rl;
+        float u[3] = {r[1] * fwd[2] - r[2] * fwd[1], r[2] * fwd[0] - r[0] * fwd[2], r[0] * fwd[1] - r[1] * fwd[0]};
+        float ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        for (int k = 0; k < 3; k++) u[k] = u[k] / ul;
+        std::memcpy(ga.right, r, sizeof r);
+        std::memcpy(ga.up, u, sizeof u);
+    }
+    std::memcpy(ga.forward, fwd, sizeof fwd);
+    ga.origin[0] = cam[4]; ga.origin[1] = cam[5]; ga.origin[2] = cam[6];
+    ga.focus = cam[7];
+    ga.aperture_radius = P.aperture_radius;
+    ga.aspect = (float)c->res_x / (float)c->res_y;
+    ga.res_x = c->res_x;
+    ga.res_y = c->res_y;
+    ga.tiles_x = (c->res_x + 7) / 8;
+    ga.n_tiles = ga.tiles_x * ((c->res_y + 7) / 8);
+    ga.counters = count ? c->d_counters : nullptr;
+
+    PathQueue q[2];
+    for (int k = 0; k < 2; k++) {
+        float4* base = c->queue_mem + (size_t)k * 4 * np;
+        q[k].s0 = base; q[k].s1 = base + np; q[k].s2 = base + 2 * np; q[k].s3 = base + 3 * np;
+    }
+
+    const bool deep = P.stack_depth > 24;
+    int ext_blocks;
+    if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, 64>, 256) : occupancy_blocks(k_extend<true, 24>, 256);
+    else ext_blocks = deep ? occupancy_blocks(k_extend<false, 64>, 256) : occupancy_blocks(k_extend<false, 24>, 256);
+    const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (np + 255) / 256);
+    const uint32_t shade_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (np + 255) / 256);
+    const uint32_t gen_grid = (uint32_t)(((uint64_t)ga.n_tiles * 64 + 255) / 256);
+
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const uint32_t frame = first_frame + f * frame_stride;
+        const bool overwrite = (c->reject_hist == 1);
+        const bool tap_frame = taps && f == 0;
+        HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 128, c->stream));
+        ga.out = q[0];
+        ga.count_out = c->ctrl;
+        ga.frame = frame;
+        {
+            StageTimer t(c, timing, RTHIP_STAGE_GENERATE);
+            hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(256), 0, c->stream, ga);
+        }
+        for (uint32_t b = 0; b < P.max_bounces; b++) {
+            ExtArgs ea{};
+            ea.sc = c->sc;
+            ea.in = q[b & 1];
+            ea.hits = c->hits;
+            ea.count_in = c->ctrl + b;
+            ea.cursor = c->ctrl + 64 + b;
+            ea.stack_depth = P.stack_depth;
+            ea.tap = (tap_frame && b == 0) ? 1u : 0u;
+            ea.tap_tri = c->tap_tri;
+            ea.tap_prim = c->tap_prim;
+            ea.tap_t = c->tap_t;
+            ea.counters = c->d_counters;
+            {
+                StageTimer t(c, timing, RTHIP_STAGE_EXTEND);
+                if (count) {
+                    if (deep) hipLaunchKernelGGL((k_extend<true, 64>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                    else hipLaunchKernelGGL((k_extend<true, 24>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                } else {
+                    if (deep) hipLaunchKernelGGL((k_extend<false, 64>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                    else hipLaunchKernelGGL((k_extend<false, 24>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                }
+            }
+            ShadeArgs sa{};
+            sa.sc = c->sc;
+            sa.in = q[b & 1];
+            sa.out = q[(b + 1) & 1];
+            sa.hits = c->hits;
+            sa.count_in = c->ctrl + b;
+            sa.count_out = c->ctrl + b + 1;
+            sa.accum = c->accum;
+            sa.tap_seed = tap_frame ? c->tap_seed : nullptr;
+            sa.term_prob = P.term_prob;
+            sa.last_bounce = (b + 1 == P.max_bounces) ? 1u : 0u;
+            sa.overwrite = overwrite ? 1u : 0u;
+            sa.counters = c->d_counters;
+            {
+                StageTimer t(c, timing, RTHIP_STAGE_SHADE);
+                if (count) hipLaunchKernelGGL((k_shade<true>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+                else hipLaunchKernelGGL((k_shade<false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+            }
+        }
+        c->reject_hist = 0; // main.rs:403
+        if (tap_frame) c->taps_valid = true;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int rthip_bind_accum(rthip_ctx* c, void* device_ptr, uint64_t n_pixels) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!device_ptr) {
+        c->accum_is_bound = false;
+        c->accum_bound_pixels = 0;
+        c->accum = c->accum_own;
+        c->buf_pixels = 0; // forces re-allocation of an owned accumulator on the next render
+        c->reject_hist = 1;
+        return RTHIP_OK;
+    }
+    if ((reinterpret_cast<uintptr_t>(device_ptr) & 15u) != 0) return fail(c, RTHIP_ERR_INVALID, "bind_accum: pointer is not 16-byte aligned");
+    if (c->have_uniforms && n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "bind_accum: %llu pixels, current resolution has %llu", (unsigned long long)n_pixels, (unsigned long long)c->n_pixels);
+    c->accum_is_bound = true;
+    c->accum_bound_pixels = n_pixels;
+    c->accum = static_cast<float4*>(device_ptr);
+    return RTHIP_OK;
+}
+
+int rthip_accum_device_ptr(rthip_ctx* c, void** device_ptr, uint64_t* n_pixels) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_uniforms) return fail(c, RTHIP_ERR_STATE, "accum_device_ptr: no frame uniforms set");
+    DeviceGuard g(c->device);
+    int rc = ensure_frame_buffers(c);
+    if (rc != RTHIP_OK) return rc;
+    if (device_ptr) *device_ptr = c->accum;
+    if (n_pixels) *n_pixels = c->n_pixels;
+    return RTHIP_OK;
+}
+
+int rthip_read_accum(rthip_ctx* c, float* rgba, uint64_t n_pixels) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!rgba) return fail(c, RTHIP_ERR_INVALID, "read_accum: null output");
+    if (!c->accum || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "read_accum: %llu pixels requested, accumulator has %llu", (unsigned long long)n_pixels, (unsigned long long)(c->accum ? c->n_pixels : 0));
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(rgba, c->accum, sizeof(float4) * n_pixels, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTHIP_OK;
+}
+
+int rthip_write_accum(rthip_ctx* c, const float* rgba, uint64_t n_pixels) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!rgba) return fail(c, RTHIP_ERR_INVALID, "write_accum: null input");
+    if (!c->have_uniforms || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "write_accum: size mismatch");
+    DeviceGuard g(c->device);
+    int rc = ensure_frame_buffers(c);
+    if (rc != RTHIP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->accum, rgba, sizeof(float4) * n_pixels, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->reject_hist = 0;
+    return RTHIP_OK;
+}
+
+int rthip_read_taps(rthip_ctx* c, int32_t* tri_idx, int32_t* prim_idx, float* t, uint32_t* final_seed, uint64_t n_pixels) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->taps_valid) return fail(c, RTHIP_ERR_STATE, "read_taps: no render with RTHIP_FLAG_TAPS has been issued");
+    if (n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "read_taps: size mismatch");
+    DeviceGuard g(c->device);
+    if (tri_idx) HIP_TRY(c, hipMemcpyAsync(tri_idx, c->tap_tri, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream));
+    if (prim_idx) HIP_TRY(c, hipMemcpyAsync(prim_idx, c->tap_prim, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream));
+    if (t) HIP_TRY(c, hipMemcpyAsync(t, c->tap_t, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream));
+    if (final_seed) HIP_TRY(c, hipMemcpyAsync(final_seed, c->tap_seed, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTHIP_OK;
+}
+
+int rthip_read_nodes_device_layout(rthip_ctx* c, void* nodes_out, uint64_t capacity, uint64_t* n_records) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "no scene uploaded");
+    if (n_records) *n_records = c->n_dev_nodes;
+    if (!nodes_out) return RTHIP_OK;
+    if (capacity < c->n_dev_nodes) return fail(c, RTHIP_ERR_INVALID, "read_nodes_device_layout: capacity %llu < %llu records", (unsigned long long)capacity, (unsigned long long)c->n_dev_nodes);
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpy(nodes_out, c->d_nodes, 32 * c->n_dev_nodes, hipMemcpyDeviceToHost));
+    return RTHIP_OK;
+}
+
+int rthip_read_node_index_map(rthip_ctx* c, uint32_t* out, uint64_t n_nodes) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "no scene uploaded");
+    if (!out || n_nodes != c->n_nodes) return fail(c, RTHIP_ERR_INVALID, "read_node_index_map: size mismatch");
+    std::memcpy(out, c->node_index_map.data(), sizeof(uint32_t) * n_nodes);
+    return RTHIP_OK;
+}
+
+int rthip_read_tri_order(rthip_ctx* c, uint32_t* out, uint64_t n_tris) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "no scene uploaded");
+    if (!out || n_tris != c->n_tris) return fail(c, RTHIP_ERR_INVALID, "read_tri_order: size mismatch");
+    for (uint64_t i = 0; i < n_tris; i++) out[i] = (uint32_t)i;
+    return RTHIP_OK;
+}
+
+int rthip_read_tris_device_layout(rthip_ctx* c, void* out, uint64_t n_tris) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "no scene uploaded");
+    if (!out || n_tris != c->n_tris) return fail(c, RTHIP_ERR_INVALID, "read_tris_device_layout: size mismatch");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpy(out, c->d_tris, 48 * n_tris, hipMemcpyDeviceToHost));
+    return RTHIP_OK;
+}
+
+int rthip_resolve(rthip_ctx* c, uint8_t* rgba8, uint64_t n_pixels, int apply_srgb_oetf) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!rgba8) return fail(c, RTHIP_ERR_INVALID, "resolve: null output");
+    if (!c->accum || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "resolve: size mismatch");
+    DeviceGuard g(c->device);
+    uint32_t* d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_out, 4 * n_pixels));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n_pixels + 255) / 256);
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, c->stream, (const float4*)c->accum, d_out, n_pixels, apply_srgb_oetf);
+    hipError_t e = hipMemcpyAsync(rgba8, d_out, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "resolve: %s", hipGetErrorString(e));
+    return RTHIP_OK;
+}
+
+int rthip_get_counters(rthip_ctx* c, rthip_counters* out) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!out) return fail(c, RTHIP_ERR_INVALID, "get_counters: null output");
+    DeviceGuard g(c->device);
+    Counters h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->rays = h.v[C_RAYS]; out->prims_visited = h.v[C_PRIMS]; out->inner_steps = h.v[C_INNER];
+    out->leaf_steps = h.v[C_LEAF]; out->tri_tests = h.v[C_TRI]; out->alpha_tests = h.v[C_ALPHA];
+    out->texel_fetches = h.v[C_TEXEL]; out->shade_calls = h.v[C_SHADE]; out->misses = h.v[C_MISS];
+    out->kills = h.v[C_KILL]; out->stack_overflows = h.v[C_OVERFLOW]; out->paths = h.v[C_PATHS];
+    return RTHIP_OK;
+}
+
+int rthip_reset_counters(rthip_ctx* c) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    return RTHIP_OK;
+}
+
+int rthip_get_timing(rthip_ctx* c, rthip_timing* out) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!out) return fail(c, RTHIP_ERR_INVALID, "get_timing: null output");
+    DeviceGuard g(c->device);
+    int rc = drain_events(c);
+    if (rc != RTHIP_OK) return rc;
+    *out = c->timing;
+    return RTHIP_OK;
+}
+
+int rthip_reset_timing(rthip_ctx* c) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    DeviceGuard g(c->device);
+    int rc = drain_events(c);
+    if (rc != RTHIP_OK) return rc;
+    c->timing = rthip_timing{};
+    return RTHIP_OK;
+}
+
+int rthip_synchronize(rthip_ctx* c) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTHIP_OK;
+}
+
+} // extern "C"
