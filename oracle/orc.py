@@ -86,6 +86,7 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(Scene), C.c_void_p, C.POINTER(Params), C.c_uint32,
                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
+        L.orc_render_rows.argtypes = L.orc_render.argtypes + [C.c_uint32, C.c_uint32]
         L.orc_trace_ray.restype = C.c_int32
         L.orc_trace_ray.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_float),
@@ -168,7 +169,7 @@ def make_scene(tris, exts, nodes, prims, texels, env, env_w, env_h):
 
 
 def render(scene, uniforms, params=None, first_frame=1, n_frames=1, frame_stride=1,
-           taps=False, n_threads=1, accum=None):
+           taps=False, n_threads=1, accum=None, row_start=0, row_step=1):
     """uniforms: 608-byte numpy buffer.  Returns dict(accum, counters[, tri, prim, t, seed])."""
     params = params or default_params()
     u = np.ascontiguousarray(uniforms).view(np.uint8).reshape(-1)
@@ -185,9 +186,9 @@ def render(scene, uniforms, params=None, first_frame=1, n_frames=1, frame_stride
         seed = np.zeros((h, w), dtype=np.uint32)
         out.update(tri=tri, prim=prim, t=t, seed=seed)
     c = Counters()
-    lib().orc_render(C.byref(scene), _ptr(u), C.byref(params), first_frame, n_frames,
-                     frame_stride, _ptr(accum), _ptr(tri), _ptr(prim), _ptr(t), _ptr(seed),
-                     C.byref(c), n_threads)
+    lib().orc_render_rows(C.byref(scene), _ptr(u), C.byref(params), first_frame, n_frames,
+                          frame_stride, _ptr(accum), _ptr(tri), _ptr(prim), _ptr(t), _ptr(seed),
+                          C.byref(c), n_threads, row_start, row_step)
     out["counters"] = c.as_dict()
     return out
 

@@ -876,7 +876,16 @@ void orc_render(const OrcScene* s, const OrcFrameUniforms* u, const OrcParams* p
                 uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride, float* accum,
                 int32_t* tap_tri, int32_t* tap_prim, float* tap_t, uint32_t* tap_seed,
                 OrcCounters* counters, int n_threads) {
+    orc_render_rows(s, u, p, first_frame, n_frames, frame_stride, accum, tap_tri, tap_prim, tap_t,
+                    tap_seed, counters, n_threads, 0, 1);
+}
+
+void orc_render_rows(const OrcScene* s, const OrcFrameUniforms* u, const OrcParams* p,
+                     uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride, float* accum,
+                     int32_t* tap_tri, int32_t* tap_prim, float* tap_t, uint32_t* tap_seed,
+                     OrcCounters* counters, int n_threads, uint32_t row_start, uint32_t row_step) {
     const uint32_t W = u->res[0], H = u->res[1];
+    if (row_step == 0) row_step = 1;
     OrcCounters total;
     memset(&total, 0, sizeof total);
     if (n_threads < 1) n_threads = 1;
@@ -895,7 +904,7 @@ void orc_render(const OrcScene* s, const OrcFrameUniforms* u, const OrcParams* p
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 4)
 #endif
-            for (int64_t y = 0; y < (int64_t)H; y++) {
+            for (int64_t y = (int64_t)row_start; y < (int64_t)H; y += (int64_t)row_step) {
                 for (uint32_t x = 0; x < W; x++) {
                     uint64_t pix = (uint64_t)x + (uint64_t)W * (uint64_t)y;
                     float rgb[3];

@@ -146,6 +146,14 @@ void orc_render(const OrcScene* s, const OrcFrameUniforms* u, const OrcParams* p
                 float* accum, int32_t* tap_tri, int32_t* tap_prim, float* tap_t,
                 uint32_t* tap_seed, OrcCounters* counters, int n_threads);
 
+/* Same, restricted to image rows row_start, row_start + row_step, ... (a bounded sample of a
+ * full-resolution frame for CPU timing); other rows of accum are left untouched. */
+void orc_render_rows(const OrcScene* s, const OrcFrameUniforms* u, const OrcParams* p,
+                     uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                     float* accum, int32_t* tap_tri, int32_t* tap_prim, float* tap_t,
+                     uint32_t* tap_seed, OrcCounters* counters, int n_threads,
+                     uint32_t row_start, uint32_t row_step);
+
 /* one trace() of an explicit world-space ray: returns tri index (-1 = miss) */
 int32_t orc_trace_ray(const OrcScene* s, const OrcParams* p, const float origin[3],
                       const float dir[3], uint32_t* seed, float* t_out, int32_t* prim_out);

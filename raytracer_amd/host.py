@@ -126,6 +126,13 @@ def trs(t=(0, 0, 0), rot_z=0.0, scale=(1, 1, 1), rot_y=0.0, rot_x=0.0):
     return np.ascontiguousarray(m.T, dtype=np.float32).reshape(16)
 
 
+def basis(t, cx, cy, cz):
+    """Column-major float[16] with the given images of the local x, y, z axes and translation t."""
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = cx, cy, cz, t
+    return np.ascontiguousarray(m.T, dtype=np.float32).reshape(16)
+
+
 class Camera:
     """input.rs:34-51.  Angles in radians; world is X forward, Z up."""
 

@@ -388,7 +388,7 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
 
     L_, W_, H1, H2 = 30.0, 12.0, 5.0, 10.0
     # floor and upper gallery floors
-    f = grid(d(96), d(48), (L_, W_), uv_scale=10.0)
+    f = grid(d(186), d(72), (L_, W_), uv_scale=10.0)
     s.add_primitive(f[0], f[1], normals=f[2], uv0=f[3], material=material(albedo_tex=stone[0], roughness=0.6))
     for side in (-1, 1):
         g = grid(d(96), d(12), (L_, 3.0), uv_scale=6.0)
@@ -396,12 +396,12 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
                         transform=host.trs((0.0, side * (W_ / 2 - 1.5), H1)))
     # outer walls (4), two storeys
     for side in (-1, 1):
-        w = grid(d(96), d(40), (L_, H2), uv_scale=8.0)
+        w = grid(d(110), d(40), (L_, H2), uv_scale=8.0)
         s.add_primitive(w[0], w[1], normals=w[2], uv0=w[3], material=material(albedo_tex=stone[2], roughness=0.9),
                         transform=host.trs((0.0, side * W_ / 2, H2 / 2), rot_x=side * np.pi / 2))
         e = grid(d(48), d(40), (W_, H2), uv_scale=8.0)
         s.add_primitive(e[0], e[1], normals=e[2], uv0=e[3], material=material(albedo_tex=stone[3], roughness=0.9),
-                        transform=host.trs((side * L_ / 2, 0.0, H2 / 2), rot_y=-side * np.pi / 2, rot_z=np.pi / 2))
+                        transform=host.basis((side * L_ / 2, 0.0, H2 / 2), (0, 1, 0), (0, 0, 1), (1, 0, 0)))
     # columns: one unique mesh per storey and side, instanced along the nave
     flute = lambda z: 1.0 + 0.25 * np.exp(-40 * z * z) + 0.3 * np.exp(-40 * (1 - z) ** 2) - 0.06 * z
     n_cols = 9
@@ -424,7 +424,7 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
     # hanging curtains (wavy cloth), three fabrics
     for k in range(6):
         wave = lambda X, Y, ph=k: 0.18 * np.sin(6 * X + ph) * (0.4 + 0.6 * (Y + 1.5) / 3.0)
-        cl = grid(d(64), d(64), (3.2, 3.0), height=wave, uv_scale=2.0)
+        cl = grid(d(84), d(84), (3.2, 3.0), height=wave, uv_scale=2.0)
         side = -1 if k % 2 else 1
         s.add_primitive(cl[0], cl[1], normals=cl[2], uv0=cl[3], uv1=cl[3] * 3.0,
                         material=material(albedo_tex=fabric[k % 3], albedo_set=k % 2, roughness=0.95),
@@ -449,7 +449,7 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
     # sculpted heads at both ends (dense meshes)
     for side in (-1, 1):
         bump = lambda p: 1.0 + 0.12 * np.sin(9 * p[:, 0]) * np.sin(8 * p[:, 1]) * np.sin(7 * p[:, 2]) + 0.2 * np.exp(-6 * (p[:, 0] - side * 0.8) ** 2)
-        hd = uv_sphere(d(128), d(96), radius=1.3, displace=bump)
+        hd = uv_sphere(d(160), d(118), radius=1.3, displace=bump)
         s.add_primitive(hd[0], hd[1], normals=hd[2], uv0=hd[3], material=material(albedo=(0.85, 0.7, 0.3, 1), metallic=1.0, roughness=0.35),
                         transform=host.trs((side * (L_ / 2 - 2.0), 0.0, 2.2)))
         ped = box((0.9, 0.9, 0.5))
@@ -466,11 +466,15 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
         s.add_primitive(lamp[0], lamp[1], normals=lamp[2], uv0=lamp[3],
                         material=material(albedo=(0.9, 0.9, 0.9, 1), emissive=(8.0, 6.0, 3.5), roughness=0.9),
                         transform=host.trs((x, 0.0, H2 - 3.8)))
+    # central basin
+    bs = torus(d(96), d(24), R=1.6, r=0.35)
+    s.add_primitive(bs[0], bs[1], normals=bs[2], uv0=bs[3], material=material(albedo_tex=stone[0], mr_tex=mr, roughness=0.5),
+                    transform=host.trs((0.0, 0.0, 0.35)))
     # roof beams across the opening
     for k in range(9):
         bm = box((0.15, W_ / 2, 0.2))
         s.add_primitive(bm[0], bm[1], normals=bm[2], uv0=bm[3], material=material(albedo_tex=stone[2], roughness=0.9),
                         transform=host.trs((-L_ / 2 + 3.0 + 3.0 * k, 0.0, H2 + 0.2)))
     s.set_env(sky_env(*env_size))
-    s.add_camera(host.Camera.look((-12.5, -0.6, 1.9), yaw=0.04, pitch=np.radians(6), fovy=np.radians(62), focus=9.0))
+    s.add_camera(host.Camera.look((-9.5, -0.6, 1.9), yaw=0.04, pitch=np.radians(6), fovy=np.radians(62), focus=9.0))
     return s
