@@ -9,15 +9,17 @@
 
 // ------------------------------------------------------------------ records in HBM
 
-// Extend-stage view of a primitive: 24 dwords, fetched through the scalar cache because the
-// primitive loop index is wave-uniform.  inv holds rows 0..2 of the four columns of the
-// uploaded inv_transform (scene.rs:185); wbox is a padded world-space bound of the root box.
+// Extend-stage view of a primitive: 24 dwords.  The first 64 bytes are what a lane needs when it
+// enters the primitive (four 16-byte loads); wbox is a padded world-space bound of the root box,
+// read through the scalar cache by the wave-uniform culling scan.  inv holds rows 0..2 of the
+// four columns of the uploaded inv_transform (scene.rs:185).
 struct PrimX {
     float    inv[12];
-    float    wbox[6];
     uint32_t root;            // device node index of the BVH root
     uint32_t alpha_settings;  // scene.rs:164, 170-177
-    uint32_t albedo_offset, albedo_size, albedo_texcoord;
+    uint32_t albedo_offset, albedo_size;
+    float    wbox[6];
+    uint32_t albedo_texcoord;
     uint32_t pad;
 };
 static_assert(sizeof(PrimX) == 96, "PrimX");
@@ -140,6 +142,26 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
     uint32_t base = 0;
     if (lane_id() == 0 && n) base = atomicAdd(counter, n);
     base = __builtin_amdgcn_readfirstlane(base);
+    return base + prefix;
+}
+
+// Same across a 256-thread block (4 waves): one atomic per block.  `scratch` is 8 dwords of LDS
+// owned by the caller.  Must be reached by every thread of the block.
+__device__ __forceinline__ uint32_t block_append(bool pred, uint32_t* counter, uint32_t* scratch) {
+    const unsigned long long m = __ballot(pred);
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 0) scratch[w] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        scratch[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = scratch[4];
+    for (uint32_t k = 0; k < w; k++) base += scratch[k];
     return base + prefix;
 }
 

@@ -81,15 +81,21 @@ struct GenArgs {
 };
 
 // One lane per pixel, one wave per 8x8 pixel tile (the reference's workgroup shape,
-// shader.wgsl:887), so a wave's camera rays are spatially coherent.
+// shader.wgsl:887), so a wave's camera rays are spatially coherent.  Queue slot = tile-order
+// index; lanes of edge tiles that fall outside the image leave a slot whose pixel word is
+// RT_NO_PIXEL, which the later stages skip, so no compaction (and no atomic) is needed here.
+#define RT_NO_PIXEL 0xFFFFFFFFu
+
 __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tile = gid >> 6, l = gid & 63u;
+    if (tile >= a.n_tiles) return;
     const uint32_t px = (tile % a.tiles_x) * 8u + (l & 7u);
     const uint32_t py = (tile / a.tiles_x) * 8u + (l >> 3);
-    const bool valid = tile < a.n_tiles && px < a.res_x && py < a.res_y;
+    const bool valid = px < a.res_x && py < a.res_y;
+    if (gid == 0) *a.count_out = a.n_tiles * 64u;
 
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, __uint_as_float(RT_NO_PIXEL));
     if (valid) {
         uint32_t seed = hash21(hash21(px, py), a.frame); // shader.wgsl:895
         // camera_ray, shader.wgsl:741-779 (basis vectors and fov factor are per-frame constants)
@@ -116,13 +122,10 @@ __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
         s0 = make_float4(origin.x, origin.y, origin.z, dir.x);
         s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(px + a.res_x * py));
     }
-    const uint32_t slot = wave_append(valid, a.count_out);
-    if (valid) {
-        a.out.s0[slot] = s0;
-        a.out.s1[slot] = s1;
-        a.out.s2[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        a.out.s3[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    a.out.s0[gid] = s0;
+    a.out.s1[gid] = s1;
+    a.out.s2[gid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    a.out.s3[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (a.counters) {
         const unsigned long long n = wave_sum(valid ? 1ull : 0ull);
         if (lane_id() == 0 && n) atomicAdd(&a.counters[C_PATHS], n);
@@ -145,108 +148,42 @@ struct ExtArgs {
     unsigned long long* counters;
 };
 
-// trace_bvh, shader.wgsl:442-525.  The traversal stack lives in LDS, one dword column per lane
-// (stack[level][lane]: conflict-free).  A popped entry is a node index whose (first, count)
-// words are re-read; the reference does not re-test the box of a popped node either.
-template <bool COUNT, int CAP>
-__device__ __forceinline__ int32_t trace_bvh(const SceneDev& sc, f3 o, f3 d, f3 idir, uint32_t root, float& t_max,
-                                             const PrimX& px, uint32_t& seed, uint32_t depth, uint32_t* stack,
-                                             bool& overflow, unsigned long long* cnt) {
-    const float4 r0 = sc.nodes[2 * (size_t)root], r1 = sc.nodes[2 * (size_t)root + 1];
-    if (COUNT) cnt[C_PRIMS]++;
-    if (hit_aabb(o, idir, r0, r1) < -0.5f) return -1;
-    uint32_t cur_first = __float_as_uint(r1.z), cur_count = __float_as_uint(r1.w);
-    float best_t = t_max;
-    int32_t best_i = -1;
-    uint32_t sp = 0;
-    const uint32_t mode = px.alpha_settings & 3u;
-    for (;;) {
-        if (cur_count > 0) {
-            if (COUNT) cnt[C_LEAF]++;
-            for (uint32_t i = cur_first; i < cur_first + cur_count; i++) {
-                const float4 a0 = sc.tris[3 * (size_t)i], a1 = sc.tris[3 * (size_t)i + 1], a2 = sc.tris[3 * (size_t)i + 2];
-                if (COUNT) cnt[C_TRI]++;
-                float u, v;
-                const float t = hit_tri(o, d, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
-                if (t >= 0.0f && t < best_t) {
-                    if (mode != 0u) { // shader.wgsl:464-487
-                        if (COUNT) cnt[C_ALPHA]++;
-                        const float b0 = (1.0f - u) - v;
-                        const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
-                        const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)i);
-                        const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
-                        float tcx = 0.0f, tcy = 0.0f;
-                        tcx += b0 * t0.x; tcy += b0 * t0.y;
-                        tcx += u * t1.x;  tcy += u * t1.y;
-                        tcx += v * t2.x;  tcy += v * t2.y;
-                        float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
-                        if (px.albedo_size != 0u) {
-                            if (COUNT) cnt[C_TEXEL]++;
-                            alpha = (float)(fetch_texel(sc, px.albedo_offset, px.albedo_size, tcx, tcy) & 255u) / 255.0f;
-                        }
-                        if (mode == 1u) {
-                            if (alpha < (float)(px.alpha_settings >> 16) / 65536.0f) continue;
-                        } else {
-                            if (rnd(seed) > alpha) continue;
-                        }
-                    }
-                    best_i = (int32_t)i;
-                    best_t = t;
-                }
-            }
-            if (sp == 0) break;
-            const uint32_t n = stack[(--sp) * RT_WAVE];
-            const float4 q = sc.nodes[2 * (size_t)n + 1];
-            cur_first = __float_as_uint(q.z);
-            cur_count = __float_as_uint(q.w);
-        } else {
-            if (COUNT) cnt[C_INNER]++;
-            const float4* pair = sc.nodes + 2 * (size_t)cur_first; // siblings: one aligned 64-byte fetch
-            const float4 l0 = pair[0], l1 = pair[1], q0 = pair[2], q1 = pair[3];
-            const float left = hit_aabb(o, idir, l0, l1);
-            const float right = hit_aabb(o, idir, q0, q1);
-            const bool lmiss = (left < -0.5f || left > best_t);
-            const bool rmiss = (right < -0.5f || right > best_t);
-            if (lmiss && rmiss) {
-                if (sp == 0) break;
-                const uint32_t n = stack[(--sp) * RT_WAVE];
-                const float4 q = sc.nodes[2 * (size_t)n + 1];
-                cur_first = __float_as_uint(q.z);
-                cur_count = __float_as_uint(q.w);
-            } else {
-                bool go_left;
-                if (lmiss) go_left = false;
-                else if (rmiss) go_left = true;
-                else {
-                    go_left = left < right;
-                    const uint32_t far_child = go_left ? cur_first + 1u : cur_first;
-                    if (sp < depth) { stack[sp * RT_WAVE] = far_child; sp++; }
-                    else { overflow = true; if (COUNT) cnt[C_OVERFLOW]++; } // shader.wgsl:306-313
-                }
-                const float4 c = go_left ? l1 : q1;
-                cur_first = __float_as_uint(c.z);
-                cur_count = __float_as_uint(c.w);
-            }
-        }
-    }
-    t_max = best_t;
-    return best_i;
-}
-
 // Conservative slab overlap of a world-space ray with a padded world-space box: a ray that
 // fails it cannot touch anything inside the primitive, so the primitive is skipped before its
 // ray transform.  Primitives that pass go through the reference's exact local-space root test.
-__device__ __forceinline__ bool overlaps_world_box(f3 o, f3 idir, const float* b) {
-    const float ax = (b[0] - o.x) * idir.x, bx = (b[3] - o.x) * idir.x;
-    const float ay = (b[1] - o.y) * idir.y, by = (b[4] - o.y) * idir.y;
-    const float az = (b[2] - o.z) * idir.z, bz = (b[5] - o.z) * idir.z;
+// The box is padded far beyond f32 rounding, so the fused form (b * idir - o * idir) is safe
+// provided idir is finite (see the caller).
+__device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float* b) {
+    const float ax = __builtin_fmaf(b[0], idir.x, -oi.x), bx = __builtin_fmaf(b[3], idir.x, -oi.x);
+    const float ay = __builtin_fmaf(b[1], idir.y, -oi.y), by = __builtin_fmaf(b[4], idir.y, -oi.y);
+    const float az = __builtin_fmaf(b[2], idir.z, -oi.z), bz = __builtin_fmaf(b[5], idir.z, -oi.z);
     const float t0 = fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz)));
     const float t1 = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
     return !(t0 > t1 || t1 < 0.0f);
 }
 
+// Lane states of the extend stage.
+#define ST_PRIM  0u   // needs its next candidate primitive (or has none left)
+#define ST_INNER 1u   // at an inner node: test the two children (shader.wgsl:496-521)
+#define ST_LEAF  2u   // inside a leaf: test one triangle per step (shader.wgsl:458-495)
+
+// trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
+//
+// Every lane runs exactly the reference's sequence of operations for its own ray -- primitives
+// in index order, children near-first, first-found-wins ties, a 'stack_depth'-entry stack whose
+// overflowing push is dropped -- but the 64 lanes of a wave do not have to be at the same point
+// of that sequence.  Per round the wave votes (ballot + popcount) for the state most lanes are
+// in and executes only that step, so inner-node steps of lanes that are in different
+// primitives, or at different depths, share the same instructions.
+//
+// Candidate primitives come from a wave-uniform scan of padded world-space bounds (scalar
+// loads), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
+// bound the ray misses changes nothing the reference would compute.
+//
 // Persistent waves: each wave pulls 64 consecutive queue slots at a time from a global cursor
-// until the queue is drained.  trace(), shader.wgsl:598-627.
+// until the queue is drained.  The traversal stack is one LDS dword column per lane
+// (stack[level][lane]: conflict-free); a popped entry is a node index whose (first, count)
+// words are re-read -- the reference does not re-test the box of a popped node either.
 template <bool COUNT, int CAP>
 __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     __shared__ uint32_t lds_stack[4 * CAP * RT_WAVE];
@@ -254,49 +191,189 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (CAP * RT_WAVE) + lane;
     const uint32_t n = *a.count_in;
     const uint32_t depth = a.stack_depth < (uint32_t)CAP ? a.stack_depth : (uint32_t)CAP;
-    unsigned long long cnt[12];
-    if (COUNT) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) cnt[k] = 0;
-    }
+    const SceneDev& sc = a.sc;
+    unsigned long long c_rays = 0, c_prims = 0, c_inner = 0, c_leaf = 0, c_tri = 0, c_alpha = 0, c_texel = 0, c_over = 0;
+
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(a.cursor, RT_WAVE);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n) break;
         const uint32_t slot = base + lane;
-        if (slot < n) {
-            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
-            const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
-            const f3 idir = rcp3(d);
-            uint32_t seed = __float_as_uint(s1.z);
-            int32_t closest_idx = -1;
-            float closest_t = 99999999.0f;
-            uint32_t closest_prim = 0;
-            bool overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
-            if (COUNT) cnt[C_RAYS]++;
-            for (uint32_t p = 0; p < a.sc.n_prims; p++) {
-                const PrimX& px = a.sc.primx[p];
-                if (!overlaps_world_box(o, idir, px.wbox)) continue;
-                const f3 td = xform_dir(d, px.inv);
-                const float scale = length(td);
-                const f3 ld = td / scale;
-                const f3 lo = xform_pos(o, px.inv);
-                const f3 lidir = rcp3(ld);
-                float new_t = closest_t * scale;
-                const int32_t idx = trace_bvh<COUNT, CAP>(a.sc, lo, ld, lidir, px.root, new_t, px, seed, depth, stack,
-                                                          overflow, cnt);
-                if (idx >= 0) {
-                    closest_t = new_t / scale;
-                    closest_idx = idx;
-                    closest_prim = p;
+        float4 s0 = make_float4(0, 0, 0, 1), s1 = make_float4(0, 0, 0, __uint_as_float(RT_NO_PIXEL));
+        if (slot < n) { s0 = a.in.s0[slot]; s1 = a.in.s1[slot]; }
+        const uint32_t pix = __float_as_uint(s1.w);
+        const bool live = slot < n && pix != RT_NO_PIXEL;
+        const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
+        uint32_t seed = __float_as_uint(s1.z);
+        int32_t closest_idx = -1;
+        float closest_t = 99999999.0f;
+        uint32_t closest_prim = 0;
+        bool overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
+        if (COUNT && live) c_rays++;
+
+        for (uint32_t chunk = 0; chunk < sc.n_prims; chunk += 128u) {
+            // ---- candidate scan (wave-uniform over primitives)
+            uint32_t mask[4];
+            {
+                // A zero direction component makes 1/d infinite and b * inf - o * inf a NaN that would
+                // silently drop that axis' bound on one side only; a huge finite reciprocal keeps the
+                // sign logic of the slab test intact (the reference's own tests keep the true 1/d).
+                const f3 r = rcp3(d);
+                const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
+                const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    uint32_t m = 0;
+                    const uint32_t p0 = chunk + 32u * w;
+                    const uint32_t pe = min(p0 + 32u, sc.n_prims);
+                    for (uint32_t p = p0; p < pe; p++)
+                        m |= (overlaps_world_box(oi, idir, sc.primx[p].wbox) ? 1u : 0u) << (p - p0);
+                    mask[w] = live ? m : 0u;
                 }
             }
+
+            // ---- per-lane traversal state
+            uint32_t st = ST_PRIM;
+            uint32_t p = 0, cur_first = 0, cur_count = 0, sp = 0, mode = 0;
+            f3 lo = o, ld = d, lidir = d;
+            float scale = 1.0f, best_t = 0.0f;
+            int32_t best_i = -1;
+
+            for (;;) {
+                const bool has_prim = (mask[0] | mask[1] | mask[2] | mask[3]) != 0u;
+                const uint32_t n_prim = (uint32_t)__popcll(__ballot(st == ST_PRIM && has_prim));
+                const uint32_t n_inner = (uint32_t)__popcll(__ballot(st == ST_INNER));
+                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(st == ST_LEAF));
+                if ((n_prim | n_inner | n_leaf) == 0u) break;
+                bool finished = false; // this lane's traversal of primitive p ended in this round
+                bool do_pop = false;
+
+                if (n_inner >= n_prim && n_inner >= n_leaf) {
+                    if (st == ST_INNER) {
+                        if (COUNT) c_inner++;
+                        const float4* pair = sc.nodes + 2 * (size_t)cur_first; // siblings: one aligned 64-byte fetch
+                        const float4 l0 = pair[0], l1 = pair[1], q0 = pair[2], q1 = pair[3];
+                        const float left = hit_aabb(lo, lidir, l0, l1);
+                        const float right = hit_aabb(lo, lidir, q0, q1);
+                        const bool lmiss = (left < -0.5f || left > best_t);
+                        const bool rmiss = (right < -0.5f || right > best_t);
+                        if (lmiss && rmiss) {
+                            do_pop = true;
+                        } else {
+                            bool go_left;
+                            if (lmiss) go_left = false;
+                            else if (rmiss) go_left = true;
+                            else {
+                                go_left = left < right;
+                                const uint32_t far_child = go_left ? cur_first + 1u : cur_first;
+                                if (sp < depth) { stack[sp * RT_WAVE] = far_child; sp++; }
+                                else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
+                            }
+                            const float4 c = go_left ? l1 : q1;
+                            cur_first = __float_as_uint(c.z);
+                            cur_count = __float_as_uint(c.w);
+                            st = cur_count > 0u ? ST_LEAF : ST_INNER;
+                            if (COUNT && cur_count > 0u) c_leaf++;
+                        }
+                    }
+                } else if (n_leaf >= n_prim) {
+                    if (st == ST_LEAF) {
+                        const size_t i = cur_first;
+                        const float4 a0 = sc.tris[3 * i], a1 = sc.tris[3 * i + 1], a2 = sc.tris[3 * i + 2];
+                        if (COUNT) c_tri++;
+                        float u, v;
+                        const float t = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
+                        if (t >= 0.0f && t < best_t) {
+                            bool accept = true;
+                            if (mode != 0u) { // shader.wgsl:464-487
+                                if (COUNT) c_alpha++;
+                                const PrimX& px = sc.primx[p];
+                                const float b0 = (1.0f - u) - v;
+                                const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
+                                const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * i);
+                                const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
+                                float tcx = 0.0f, tcy = 0.0f;
+                                tcx += b0 * t0.x; tcy += b0 * t0.y;
+                                tcx += u * t1.x;  tcy += u * t1.y;
+                                tcx += v * t2.x;  tcy += v * t2.y;
+                                float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
+                                const uint32_t asize = px.albedo_size;
+                                if (asize != 0u) {
+                                    if (COUNT) c_texel++;
+                                    alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
+                                }
+                                if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
+                                else accept = !(rnd(seed) > alpha);
+                            }
+                            if (accept) { best_i = (int32_t)cur_first; best_t = t; }
+                        }
+                        cur_first++;
+                        cur_count--;
+                        if (cur_count == 0u) do_pop = true;
+                    }
+                } else {
+                    if (st == ST_PRIM && has_prim) {
+                        // next candidate in index order
+                        uint32_t k;
+                        if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
+                        else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
+                        else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
+                        else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
+                        p = chunk + k;
+                        const float4* pq = reinterpret_cast<const float4*>(sc.primx + p);
+                        const float4 m0 = pq[0], m1 = pq[1], m2 = pq[2], m3 = pq[3];
+                        const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
+                        // transform_ray + scale factor, shader.wgsl:604-607
+                        const f3 td = xform_dir(d, inv);
+                        scale = length(td);
+                        ld = td / scale;
+                        lo = xform_pos(o, inv);
+                        lidir = rcp3(ld);
+                        const uint32_t root = __float_as_uint(m3.x);
+                        mode = __float_as_uint(m3.y) & 3u;
+                        const float4 r0 = sc.nodes[2 * (size_t)root], r1 = sc.nodes[2 * (size_t)root + 1];
+                        if (COUNT) c_prims++;
+                        if (!(hit_aabb(lo, lidir, r0, r1) < -0.5f)) { // shader.wgsl:448
+                            best_t = closest_t * scale;
+                            best_i = -1;
+                            sp = 0;
+                            cur_first = __float_as_uint(r1.z);
+                            cur_count = __float_as_uint(r1.w);
+                            st = cur_count > 0u ? ST_LEAF : ST_INNER;
+                            if (COUNT && cur_count > 0u) c_leaf++;
+                        }
+                    }
+                }
+
+                if (do_pop) {
+                    if (sp == 0u) {
+                        finished = true;
+                    } else {
+                        const uint32_t nd = stack[(--sp) * RT_WAVE];
+                        const float4 q = sc.nodes[2 * (size_t)nd + 1];
+                        cur_first = __float_as_uint(q.z);
+                        cur_count = __float_as_uint(q.w);
+                        st = cur_count > 0u ? ST_LEAF : ST_INNER;
+                        if (COUNT && cur_count > 0u) c_leaf++;
+                    }
+                }
+                if (finished) { // shader.wgsl:610-614
+                    if (best_i >= 0) {
+                        closest_t = best_t / scale;
+                        closest_idx = best_i;
+                        closest_prim = p;
+                    }
+                    st = ST_PRIM;
+                }
+            }
+        }
+
+        if (slot < n) {
             a.hits[slot] = make_float4(closest_t, __int_as_float(closest_idx),
                                        __uint_as_float(closest_prim | (overflow ? 0x80000000u : 0u)),
                                        __uint_as_float(seed));
-            if (a.tap) {
-                const uint32_t pix = __float_as_uint(s1.w);
+            if (a.tap && live) {
                 a.tap_tri[pix] = closest_idx;
                 a.tap_prim[pix] = closest_idx >= 0 ? (int32_t)closest_prim : -1;
                 a.tap_t[pix] = closest_t;
@@ -304,10 +381,12 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
         }
     }
     if (COUNT) {
+        const unsigned long long v[8] = {c_rays, c_prims, c_inner, c_leaf, c_tri, c_alpha, c_texel, c_over};
+        const int idx[8] = {C_RAYS, C_PRIMS, C_INNER, C_LEAF, C_TRI, C_ALPHA, C_TEXEL, C_OVERFLOW};
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-            const unsigned long long s = wave_sum(cnt[k]);
-            if (lane == 0 && s) atomicAdd(&a.counters[k], s);
+        for (int k = 0; k < 8; k++) {
+            const unsigned long long sum = wave_sum(v[k]);
+            if (lane == 0 && sum) atomicAdd(&a.counters[idx[k]], sum);
         }
     }
 }
@@ -357,14 +436,15 @@ __device__ __forceinline__ f3 to_linear(f3 c) { // shader.wgsl:725-728
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    __shared__ uint32_t scratch[8];
     const uint32_t n = *a.count_in;
-    const uint32_t n_pad = (n + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
+    const uint32_t n_pad = (n + 255u) & ~255u; // whole blocks stay in the loop together
     const uint32_t stride = gridDim.x * blockDim.x;
     unsigned long long c_shade = 0, c_miss = 0, c_kill = 0, c_texel = 0;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_pad; slot += stride) {
         bool survive = false;
         float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
-        if (slot < n) {
+        if (slot < n && __float_as_uint(a.in.s1[slot].w) != RT_NO_PIXEL) {
             const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
             const float4 h = a.hits[slot];
             f3 origin = F3(s0.x, s0.y, s0.z), dir = F3(s0.w, s1.x, s1.y);
@@ -502,7 +582,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
                 if (a.tap_seed) a.tap_seed[pix] = seed;
             }
         }
-        const uint32_t dst = wave_append(survive, a.count_out);
+        const uint32_t dst = block_append(survive, a.count_out, scratch);
         if (survive) {
             a.out.s0[dst] = o0;
             a.out.s1[dst] = o1;

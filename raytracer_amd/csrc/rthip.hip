@@ -65,6 +65,7 @@ struct rthip_ctx {
     uint32_t* tap_seed = nullptr;
     bool      taps_valid = false;
     uint64_t  buf_pixels = 0;
+    uint64_t  queue_cap = 0;
 
     unsigned long long* d_counters = nullptr;
 
@@ -158,8 +159,11 @@ int ensure_frame_buffers(rthip_ctx* c) {
     const uint64_t n = c->n_pixels;
     if (c->buf_pixels == n && c->queue_mem) return RTHIP_OK;
     free_frame_buffers(c);
-    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * n));
-    HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * n));
+    // queue slots are handed out per 8x8 pixel tile, so edge tiles pad the capacity
+    const uint64_t cap = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
+    c->queue_cap = cap;
+    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * cap));
+    HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * cap));
     HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
     HIP_TRY(c, hipMalloc((void**)&c->tap_prim, sizeof(int32_t) * n));
     HIP_TRY(c, hipMalloc((void**)&c->tap_t, sizeof(float) * n));
@@ -501,8 +505,6 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
     const bool taps = (P.flags & RTHIP_FLAG_TAPS) != 0;
     const bool timing = (P.flags & RTHIP_FLAG_TIMING) != 0;
-    const uint64_t np = c->n_pixels;
-
     // camera constants of camera_ray (shader.wgsl:744-755), identical for every pixel
     float cam[12];
     std::memcpy(cam, c->uniforms + 512, 48);
@@ -534,16 +536,17 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
 
     PathQueue q[2];
     for (int k = 0; k < 2; k++) {
-        float4* base = c->queue_mem + (size_t)k * 4 * np;
-        q[k].s0 = base; q[k].s1 = base + np; q[k].s2 = base + 2 * np; q[k].s3 = base + 3 * np;
+        const uint64_t cap = c->queue_cap;
+        float4* base = c->queue_mem + (size_t)k * 4 * cap;
+        q[k].s0 = base; q[k].s1 = base + cap; q[k].s2 = base + 2 * cap; q[k].s3 = base + 3 * cap;
     }
 
     const bool deep = P.stack_depth > 24;
     int ext_blocks;
     if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, 64>, 256) : occupancy_blocks(k_extend<true, 24>, 256);
     else ext_blocks = deep ? occupancy_blocks(k_extend<false, 64>, 256) : occupancy_blocks(k_extend<false, 24>, 256);
-    const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (np + 255) / 256);
-    const uint32_t shade_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (np + 255) / 256);
+    const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (c->queue_cap + 255) / 256);
+    const uint32_t shade_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (c->queue_cap + 255) / 256);
     const uint32_t gen_grid = (uint32_t)(((uint64_t)ga.n_tiles * 64 + 255) / 256);
 
     for (uint32_t f = 0; f < n_frames; f++) {

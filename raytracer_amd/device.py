@@ -12,7 +12,7 @@ import numpy as np
 from . import layouts as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "librthip.so")
+_LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
 FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
 STAGES = ("generate", "extend", "shade", "resolve")
