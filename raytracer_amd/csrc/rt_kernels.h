@@ -153,7 +153,7 @@ struct ExtArgs {
 // ray transform.  Primitives that pass go through the reference's exact local-space root test.
 // The box is padded far beyond f32 rounding, so the fused form (b * idir - o * idir) is safe
 // provided idir is finite (see the caller).
-__device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float* b) {
+__device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (&b)[6]) {
     const float ax = __builtin_fmaf(b[0], idir.x, -oi.x), bx = __builtin_fmaf(b[3], idir.x, -oi.x);
     const float ay = __builtin_fmaf(b[1], idir.y, -oi.y), by = __builtin_fmaf(b[4], idir.y, -oi.y);
     const float az = __builtin_fmaf(b[2], idir.z, -oi.z), bz = __builtin_fmaf(b[5], idir.z, -oi.z);
@@ -166,6 +166,34 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float* 
 #define ST_PRIM  0u   // needs its next candidate primitive (or has none left)
 #define ST_INNER 1u   // at an inner node: test the two children (shader.wgsl:496-521)
 #define ST_LEAF  2u   // inside a leaf: test one triangle per step (shader.wgsl:458-495)
+
+// Inner-node steps a wave runs back to back once the vote picked them (lanes that leave the
+// inner state sit the remaining ones out); amortises the vote's scalar work.
+#define RT_INNER_BURST 3
+
+// Loads through the scalar cache: the address is wave-uniform and the data is never written by
+// a kernel, which the constant address space tells the compiler.
+typedef const __attribute__((address_space(4))) float* rt_cfloat_p;
+
+// 16-byte load at base + 32-bit byte offset (SGPR base + VGPR offset addressing).
+__device__ __forceinline__ float4 ld16(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float4*>(static_cast<const char*>(base) + byte_off);
+}
+
+// intersect_aabb (shader.wgsl:415-438) with the origin-inside test taken from the signs of the
+// same differences the slab test needs: o >= min  <=>  min - o <= 0, o < max  <=>  max - o > 0
+// (f32 subtraction never flips or drops the sign of an exact non-zero difference).
+__device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1) {
+    const float d0x = q0.x - o.x, d0y = q0.y - o.y, d0z = q0.z - o.z;
+    const float d1x = q0.w - o.x, d1y = q1.x - o.y, d1z = q1.y - o.z;
+    const bool inside = fmaxf(d0x, fmaxf(d0y, d0z)) <= 0.0f && fminf(d1x, fminf(d1y, d1z)) > 0.0f;
+    const float ax = d0x * idir.x, ay = d0y * idir.y, az = d0z * idir.z;
+    const float bx = d1x * idir.x, by = d1y * idir.y, bz = d1z * idir.z;
+    const float t0 = fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float t1 = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    const float r = (t0 > t1 || t0 < 0.0f) ? -1.0f : t0;
+    return inside ? 0.0f : r;
+}
 
 // trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
 //
@@ -192,6 +220,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     const uint32_t n = *a.count_in;
     const uint32_t depth = a.stack_depth < (uint32_t)CAP ? a.stack_depth : (uint32_t)CAP;
     const SceneDev& sc = a.sc;
+    const void* const nodes = sc.nodes;
+    const void* const tris = sc.tris;
     unsigned long long c_rays = 0, c_prims = 0, c_inner = 0, c_leaf = 0, c_tri = 0, c_alpha = 0, c_texel = 0, c_over = 0;
 
     for (;;) {
@@ -227,8 +257,11 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                     uint32_t m = 0;
                     const uint32_t p0 = chunk + 32u * w;
                     const uint32_t pe = min(p0 + 32u, sc.n_prims);
-                    for (uint32_t p = p0; p < pe; p++)
-                        m |= (overlaps_world_box(oi, idir, sc.primx[p].wbox) ? 1u : 0u) << (p - p0);
+                    for (uint32_t p = p0; p < pe; p++) {
+                        const rt_cfloat_p wb = (rt_cfloat_p)(sc.primx[p].wbox);
+                        const float b[6] = {wb[0], wb[1], wb[2], wb[3], wb[4], wb[5]};
+                        m |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (p - p0);
+                    }
                     mask[w] = live ? m : 0u;
                 }
             }
@@ -240,47 +273,67 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
             float scale = 1.0f, best_t = 0.0f;
             int32_t best_i = -1;
 
+            // the traversal of primitive p ended: shader.wgsl:610-614
+            auto finish = [&]() {
+                if (best_i >= 0) {
+                    closest_t = best_t / scale;
+                    closest_idx = best_i;
+                    closest_prim = p;
+                }
+                st = ST_PRIM;
+            };
+            auto enter = [&](uint32_t first, uint32_t count) {
+                cur_first = first;
+                cur_count = count;
+                st = count > 0u ? ST_LEAF : ST_INNER;
+                if (COUNT && count > 0u) c_leaf++;
+            };
+            auto pop_or_finish = [&]() {
+                if (sp == 0u) {
+                    finish();
+                } else {
+                    const uint32_t nd = stack[(--sp) * RT_WAVE];
+                    const float4 q = ld16(nodes, nd * 32u + 16u);
+                    enter(__float_as_uint(q.z), __float_as_uint(q.w));
+                }
+            };
+
             for (;;) {
                 const bool has_prim = (mask[0] | mask[1] | mask[2] | mask[3]) != 0u;
                 const uint32_t n_prim = (uint32_t)__popcll(__ballot(st == ST_PRIM && has_prim));
                 const uint32_t n_inner = (uint32_t)__popcll(__ballot(st == ST_INNER));
                 const uint32_t n_leaf = (uint32_t)__popcll(__ballot(st == ST_LEAF));
                 if ((n_prim | n_inner | n_leaf) == 0u) break;
-                bool finished = false; // this lane's traversal of primitive p ended in this round
-                bool do_pop = false;
 
                 if (n_inner >= n_prim && n_inner >= n_leaf) {
-                    if (st == ST_INNER) {
-                        if (COUNT) c_inner++;
-                        const float4* pair = sc.nodes + 2 * (size_t)cur_first; // siblings: one aligned 64-byte fetch
-                        const float4 l0 = pair[0], l1 = pair[1], q0 = pair[2], q1 = pair[3];
-                        const float left = hit_aabb(lo, lidir, l0, l1);
-                        const float right = hit_aabb(lo, lidir, q0, q1);
-                        const bool lmiss = (left < -0.5f || left > best_t);
-                        const bool rmiss = (right < -0.5f || right > best_t);
-                        if (lmiss && rmiss) {
-                            do_pop = true;
-                        } else {
-                            bool go_left;
-                            if (lmiss) go_left = false;
-                            else if (rmiss) go_left = true;
-                            else {
-                                go_left = left < right;
-                                const uint32_t far_child = go_left ? cur_first + 1u : cur_first;
-                                if (sp < depth) { stack[sp * RT_WAVE] = far_child; sp++; }
-                                else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
+#pragma unroll 1
+                    for (int burst = 0; burst < RT_INNER_BURST; burst++) {
+                        if (st == ST_INNER) {
+                            if (COUNT) c_inner++;
+                            const uint32_t off = cur_first * 32u; // siblings: one aligned 64-byte fetch
+                            const float4 l0 = ld16(nodes, off), l1 = ld16(nodes, off + 16u);
+                            const float4 q0 = ld16(nodes, off + 32u), q1 = ld16(nodes, off + 48u);
+                            const float left = hit_aabb_s(lo, lidir, l0, l1);
+                            const float right = hit_aabb_s(lo, lidir, q0, q1);
+                            const bool lmiss = (left < -0.5f || left > best_t);
+                            const bool rmiss = (right < -0.5f || right > best_t);
+                            if (lmiss && rmiss) {
+                                pop_or_finish();
+                            } else {
+                                const bool go_left = rmiss ? true : (lmiss ? false : left < right);
+                                if (!lmiss && !rmiss) {
+                                    if (sp < depth) { stack[sp * RT_WAVE] = go_left ? cur_first + 1u : cur_first; sp++; }
+                                    else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
+                                }
+                                enter(__float_as_uint(go_left ? l1.z : q1.z), __float_as_uint(go_left ? l1.w : q1.w));
                             }
-                            const float4 c = go_left ? l1 : q1;
-                            cur_first = __float_as_uint(c.z);
-                            cur_count = __float_as_uint(c.w);
-                            st = cur_count > 0u ? ST_LEAF : ST_INNER;
-                            if (COUNT && cur_count > 0u) c_leaf++;
                         }
+                        if (__ballot(st == ST_INNER) == 0ull) break;
                     }
                 } else if (n_leaf >= n_prim) {
                     if (st == ST_LEAF) {
-                        const size_t i = cur_first;
-                        const float4 a0 = sc.tris[3 * i], a1 = sc.tris[3 * i + 1], a2 = sc.tris[3 * i + 2];
+                        const uint32_t off = cur_first * 48u;
+                        const float4 a0 = ld16(tris, off), a1 = ld16(tris, off + 16u), a2 = ld16(tris, off + 32u);
                         if (COUNT) c_tri++;
                         float u, v;
                         const float t = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
@@ -291,7 +344,7 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                                 const PrimX& px = sc.primx[p];
                                 const float b0 = (1.0f - u) - v;
                                 const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
-                                const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * i);
+                                const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)cur_first);
                                 const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
                                 float tcx = 0.0f, tcy = 0.0f;
                                 tcx += b0 * t0.x; tcy += b0 * t0.y;
@@ -310,7 +363,7 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                         }
                         cur_first++;
                         cur_count--;
-                        if (cur_count == 0u) do_pop = true;
+                        if (cur_count == 0u) pop_or_finish();
                     }
                 } else {
                     if (st == ST_PRIM && has_prim) {
@@ -321,8 +374,9 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                         else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
                         else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
                         p = chunk + k;
-                        const float4* pq = reinterpret_cast<const float4*>(sc.primx + p);
-                        const float4 m0 = pq[0], m1 = pq[1], m2 = pq[2], m3 = pq[3];
+                        const uint32_t poff = p * (uint32_t)sizeof(PrimX);
+                        const float4 m0 = ld16(sc.primx, poff), m1 = ld16(sc.primx, poff + 16u), m2 = ld16(sc.primx, poff + 32u),
+                                     m3 = ld16(sc.primx, poff + 48u);
                         const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
                         // transform_ray + scale factor, shader.wgsl:604-607
                         const f3 td = xform_dir(d, inv);
@@ -332,39 +386,15 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                         lidir = rcp3(ld);
                         const uint32_t root = __float_as_uint(m3.x);
                         mode = __float_as_uint(m3.y) & 3u;
-                        const float4 r0 = sc.nodes[2 * (size_t)root], r1 = sc.nodes[2 * (size_t)root + 1];
+                        const float4 r0 = ld16(nodes, root * 32u), r1 = ld16(nodes, root * 32u + 16u);
                         if (COUNT) c_prims++;
-                        if (!(hit_aabb(lo, lidir, r0, r1) < -0.5f)) { // shader.wgsl:448
+                        if (!(hit_aabb_s(lo, lidir, r0, r1) < -0.5f)) { // shader.wgsl:448
                             best_t = closest_t * scale;
                             best_i = -1;
                             sp = 0;
-                            cur_first = __float_as_uint(r1.z);
-                            cur_count = __float_as_uint(r1.w);
-                            st = cur_count > 0u ? ST_LEAF : ST_INNER;
-                            if (COUNT && cur_count > 0u) c_leaf++;
+                            enter(__float_as_uint(r1.z), __float_as_uint(r1.w));
                         }
                     }
-                }
-
-                if (do_pop) {
-                    if (sp == 0u) {
-                        finished = true;
-                    } else {
-                        const uint32_t nd = stack[(--sp) * RT_WAVE];
-                        const float4 q = sc.nodes[2 * (size_t)nd + 1];
-                        cur_first = __float_as_uint(q.z);
-                        cur_count = __float_as_uint(q.w);
-                        st = cur_count > 0u ? ST_LEAF : ST_INNER;
-                        if (COUNT && cur_count > 0u) c_leaf++;
-                    }
-                }
-                if (finished) { // shader.wgsl:610-614
-                    if (best_i >= 0) {
-                        closest_t = best_t / scale;
-                        closest_idx = best_i;
-                        closest_prim = p;
-                    }
-                    st = ST_PRIM;
                 }
             }
         }

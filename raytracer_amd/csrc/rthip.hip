@@ -299,6 +299,10 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (s->n_texels && !s->texels) return fail(c, RTHIP_ERR_INVALID, "upload_scene: null texel array");
     if (s->n_nodes >= 0x7FFFFFFFull || s->n_tris >= 0x7FFFFFFFull || s->n_prims >= 0x7FFFFFFFu)
         return fail(c, RTHIP_ERR_INVALID, "upload_scene: more than 2^31-1 nodes, triangles or primitives");
+    // the kernels address nodes, triangles and primitives with 32-bit byte offsets
+    if ((s->n_nodes + s->n_prims + 1) * 32ull >= 0xFFFFFFFFull || s->n_tris * 48ull >= 0xFFFFFFFFull || s->n_prims * 96ull >= 0xFFFFFFFFull)
+        return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: node or triangle array of 4 GiB or more (%llu nodes, %llu triangles)",
+                    (unsigned long long)s->n_nodes, (unsigned long long)s->n_tris);
 
     const HostNode*   nodes = static_cast<const HostNode*>(s->nodes);
     const HostTri*    tris = static_cast<const HostTri*>(s->tris);
