@@ -61,7 +61,7 @@ uint32_t bvh_build(const float* tris, uint32_t offset, uint32_t size, Node* node
 int add_primitive(Scene& s, const float* positions, uint32_t n_verts, const uint32_t* indices,
                   uint64_t n_indices, const float* normals, const float* uv0, const float* uv1,
                   const uint32_t* colors, const Material& material, const float transform[16],
-                  uint32_t* out_prim);
+                  uint32_t* out_prim, bool normals_are_unit = false);
 int add_instance(Scene& s, uint32_t prim, const float transform[16], uint32_t* out_prim);
 int add_texture(Scene& s, const uint8_t* rgba8, uint32_t w, uint32_t h, TexRef* out);
 void mat4_mul(const float a[16], const float b[16], float out[16]);

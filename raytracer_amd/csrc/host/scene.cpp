@@ -135,7 +135,7 @@ int add_texture(Scene& s, const uint8_t* rgba8, uint32_t w, uint32_t h, TexRef* 
 int add_primitive(Scene& s, const float* positions, uint32_t n_verts, const uint32_t* indices,
                   uint64_t n_indices, const float* normals, const float* uv0, const float* uv1,
                   const uint32_t* colors, const Material& material, const float transform[16],
-                  uint32_t* out_prim) {
+                  uint32_t* out_prim, bool normals_are_unit) {
     if (!positions || !indices || !transform) { set_error("add_primitive: null argument"); return RTHOST_ERR_INVALID; }
     const uint64_t n_new = n_indices / 3; // scene.rs:520: trailing partial triple is dropped
     if (s.tris.size() + n_new > 0xFFFFFFFFull) { set_error("add_primitive: triangle index overflows u32"); return RTHOST_ERR_LIMIT; }
@@ -148,7 +148,7 @@ int add_primitive(Scene& s, const float* positions, uint32_t n_verts, const uint
         for (uint32_t v = 0; v < n_verts; v++) {
             const float* n = normals + (size_t)v * 3;
             const float len = std::sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
-            const float rl = 1.0f / len;
+            const float rl = normals_are_unit ? 1.0f : 1.0f / len;
             const float nn[3] = {n[0] * rl, n[1] * rl, n[2] * rl};
             pack_oct(nn, &packed_normals[(size_t)v * 2]);
         }

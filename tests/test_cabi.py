@@ -1,0 +1,63 @@
+"""The two shared libraries load without a GPU and export exactly what include/*.h declares;
+no compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from raytracer_amd import device, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s_\w+)\s*\(" % prefix, text)))
+
+
+def test_rthip_exports_every_declared_symbol():
+    names = declared("rthip.h", "rthip")
+    assert len(names) >= 24
+    lib = device.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(device.EXPORTS) == names
+
+
+def test_rthost_exports_every_declared_symbol():
+    names = declared("rthost.h", "rthost")
+    assert len(names) >= 24
+    lib = host.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a gfx950 device creating a context fails loudly; nothing renders on the CPU."""
+    lib = device.lib()
+    if lib.rthip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    rc = lib.rthip_create(0, ctypes.byref(h))
+    assert rc == -4 and not h.value
+    assert b"no HIP device" in lib.rthip_last_error(None)
+    with pytest.raises(device.RtHipError):
+        device.Context(0)
+
+
+def test_default_params_are_the_reference_constants():
+    p = device.default_params()
+    assert (p.max_bounces, p.term_prob, p.stack_depth, p.enable_sun, p.flags) == (8, 0.5, 23, 0, 0)
+    assert abs(p.aperture_radius - 0.025) < 1e-9
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under raytracer_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "rt_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
