@@ -220,6 +220,12 @@ def main():
             },
             "counters_per_ray": {k: round(counters[k] / max(rays_local, 1), 3)
                                  for k in ("prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests")},
+            "extend_simd_utilisation": {
+                "prim_steps": round(counters["prims_visited"] / max(64 * counters["rounds_prim"], 1), 3),
+                "inner_steps": round(counters["inner_steps"] / max(64 * counters["rounds_inner"], 1), 3),
+                "tri_steps": round(counters["tri_tests"] / max(64 * counters["rounds_leaf"], 1), 3),
+                "rounds_per_batch": round((counters["rounds_prim"] + counters["rounds_inner"] + counters["rounds_leaf"]) / max(counters["batches"], 1), 1),
+            },
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arrays, uniforms, p_plain)

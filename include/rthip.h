@@ -80,6 +80,12 @@ typedef struct {
     uint64_t kills;           /* paths ended by the termination draw, shader.wgsl:907-909       */
     uint64_t stack_overflows; /* dropped pushes                                                 */
     uint64_t paths;           /* camera rays generated                                          */
+    /* wave-level efficiency of the extend stage: how many times a wave executed each kind of
+     * step (64 lanes each); lane steps / (rounds * 64) is the SIMD utilisation of that step   */
+    uint64_t rounds_prim;     /* primitive-entry steps; lane steps = prims_visited              */
+    uint64_t rounds_inner;    /* inner-node steps;      lane steps = inner_steps                */
+    uint64_t rounds_leaf;     /* triangle-test steps;   lane steps = tri_tests                  */
+    uint64_t batches;         /* 64-ray batches pulled from the queue                           */
 } rthip_counters;
 
 #define RTHIP_STAGE_GENERATE 0

@@ -75,29 +75,34 @@ struct GenArgs {
     float     up[3];
     float     fov_factor, aspect, focus, aperture_radius;
     uint32_t  res_x, res_y, tiles_x, n_tiles;
-    uint32_t  frame;
-    uint32_t  pad;
+    uint32_t  first_frame, frame_stride, n_frames; // frames first, first + stride, ... share this launch
+    uint32_t  n_pixels;
     unsigned long long* counters; // may be null
 };
 
-// One lane per pixel, one wave per 8x8 pixel tile (the reference's workgroup shape,
-// shader.wgsl:887), so a wave's camera rays are spatially coherent.  Queue slot = tile-order
-// index; lanes of edge tiles that fall outside the image leave a slot whose pixel word is
-// RT_NO_PIXEL, which the later stages skip, so no compaction (and no atomic) is needed here.
+// One lane per pixel and frame, one wave per 8x8 pixel tile (the reference's workgroup shape,
+// shader.wgsl:887), so a wave's camera rays are spatially coherent.  Several frames (samples
+// per pixel) are generated into one queue so that the later, thinner bounces still fill the
+// chip.  Queue slot = (frame slot, tile, lane); lanes of edge tiles that fall outside the image
+// leave a slot whose pixel word is RT_NO_PIXEL, which the later stages skip, so no compaction
+// (and no atomic) is needed here.  The pixel word of a path is frame_slot * n_pixels + pixel:
+// the index of its private accumulation slot.
 #define RT_NO_PIXEL 0xFFFFFFFFu
 
 __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tile = gid >> 6, l = gid & 63u;
-    if (tile >= a.n_tiles) return;
+    const uint32_t per_frame = a.n_tiles * 64u;
+    const uint32_t fs = gid / per_frame, local = gid - fs * per_frame;
+    if (fs >= a.n_frames) return;
+    const uint32_t tile = local >> 6, l = local & 63u;
     const uint32_t px = (tile % a.tiles_x) * 8u + (l & 7u);
     const uint32_t py = (tile / a.tiles_x) * 8u + (l >> 3);
     const bool valid = px < a.res_x && py < a.res_y;
-    if (gid == 0) *a.count_out = a.n_tiles * 64u;
+    if (gid == 0) *a.count_out = per_frame * a.n_frames;
 
     float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, __uint_as_float(RT_NO_PIXEL));
     if (valid) {
-        uint32_t seed = hash21(hash21(px, py), a.frame); // shader.wgsl:895
+        uint32_t seed = hash21(hash21(px, py), a.first_frame + fs * a.frame_stride); // shader.wgsl:895
         // camera_ray, shader.wgsl:741-779 (basis vectors and fov factor are per-frame constants)
         const f3 origin0 = F3(a.origin[0], a.origin[1], a.origin[2]);
         const f3 forward = F3(a.forward[0], a.forward[1], a.forward[2]);
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
         pixel_pos = pixel_pos + dir * (a.focus - 1.0f);
         dir = normalize(pixel_pos - origin);
         s0 = make_float4(origin.x, origin.y, origin.z, dir.x);
-        s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(px + a.res_x * py));
+        s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(fs * a.n_pixels + px + a.res_x * py));
     }
     a.out.s0[gid] = s0;
     a.out.s1[gid] = s1;
@@ -141,7 +146,9 @@ struct ExtArgs {
     const uint32_t* count_in;
     uint32_t* cursor;
     uint32_t  stack_depth;
-    uint32_t  tap;            // 1: record primary hits per pixel
+    uint32_t  tap;            // 1: record primary hits per pixel (paths of frame slot 0 only)
+    uint32_t  n_pixels;
+    uint32_t  pad;
     int32_t*  tap_tri;
     int32_t*  tap_prim;
     float*    tap_t;
@@ -163,13 +170,26 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 }
 
 // Lane states of the extend stage.
-#define ST_PRIM  0u   // needs its next candidate primitive (or has none left)
+#define ST_PRIM  0u   // between primitives, with at least one candidate left in its mask
 #define ST_INNER 1u   // at an inner node: test the two children (shader.wgsl:496-521)
 #define ST_LEAF  2u   // inside a leaf: test one triangle per step (shader.wgsl:458-495)
+#define ST_SCAN  3u   // has a ray, needs the candidate mask of primitives [cb, cb + 128)
+#define ST_DONE  4u   // its ray is finished and written back: wants a new one
+#define ST_IDLE  5u   // the queue is drained: nothing more to do
 
 // Inner-node steps a wave runs back to back once the vote picked them (lanes that leave the
 // inner state sit the remaining ones out); amortises the vote's scalar work.
+#ifndef RT_INNER_BURST
 #define RT_INNER_BURST 3
+#endif
+// Lanes that must be waiting before the wave spends a refill (queue fetch) or a candidate scan
+// on them while other lanes still have traversal work.
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 24
+#endif
+#ifndef RT_SCAN_LANES
+#define RT_SCAN_LANES 24
+#endif
 
 // Loads through the scalar cache: the address is wave-uniform and the data is never written by
 // a kernel, which the constant address space tells the compiler.
@@ -200,18 +220,23 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // Every lane runs exactly the reference's sequence of operations for its own ray -- primitives
 // in index order, children near-first, first-found-wins ties, a 'stack_depth'-entry stack whose
 // overflowing push is dropped -- but the 64 lanes of a wave do not have to be at the same point
-// of that sequence.  Per round the wave votes (ballot + popcount) for the state most lanes are
-// in and executes only that step, so inner-node steps of lanes that are in different
-// primitives, or at different depths, share the same instructions.
+// of that sequence, nor on rays that were fetched together.  Per round the wave votes (ballot +
+// popcount) for the state most lanes are in and executes only that step, so inner-node steps of
+// lanes that are in different primitives, at different depths or on different rays share the
+// same instructions.
+//
+// Persistent waves with lane refill: a wave reserves 64 consecutive queue slots per atomic on
+// a global cursor; a lane whose ray is finished writes its hit record and, once enough lanes
+// are waiting, the waiting lanes take the next reserved slots.  No lane idles until the
+// slowest ray of a batch is done.
 //
 // Candidate primitives come from a wave-uniform scan of padded world-space bounds (scalar
 // loads), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
 // bound the ray misses changes nothing the reference would compute.
 //
-// Persistent waves: each wave pulls 64 consecutive queue slots at a time from a global cursor
-// until the queue is drained.  The traversal stack is one LDS dword column per lane
-// (stack[level][lane]: conflict-free); a popped entry is a node index whose (first, count)
-// words are re-read -- the reference does not re-test the box of a popped node either.
+// The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free); a
+// popped entry is a node index whose (first, count) words are re-read -- the reference does
+// not re-test the box of a popped node either.
 template <bool COUNT, int CAP>
 __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     __shared__ uint32_t lds_stack[4 * CAP * RT_WAVE];
@@ -223,190 +248,254 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     const void* const nodes = sc.nodes;
     const void* const tris = sc.tris;
     unsigned long long c_rays = 0, c_prims = 0, c_inner = 0, c_leaf = 0, c_tri = 0, c_alpha = 0, c_texel = 0, c_over = 0;
+    unsigned long long r_prim = 0, r_inner = 0, r_leaf = 0, r_batch = 0; // wave-uniform
+
+    // wave-uniform: the reserved run of queue slots not yet handed to a lane
+    uint32_t run_next = 0, run_end = 0;
+    bool drained = false;
+
+    // per-lane
+    uint32_t st = ST_DONE;
+    uint32_t slot = 0, pix = RT_NO_PIXEL, seed = 0;
+    f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+    int32_t closest_idx = -1;
+    float closest_t = 99999999.0f;
+    uint32_t closest_prim = 0;
+    bool overflow = false;
+    uint32_t mask[4] = {0, 0, 0, 0};
+    uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes
+    uint32_t p = 0, cur_first = 0, cur_count = 0, sp = 0, mode = 0;
+    f3 lo = o, ld = d, lidir = d;
+    float scale = 1.0f, best_t = 0.0f;
+    int32_t best_i = -1;
+
+    // the ray is finished: write its hit record, wait for a new ray
+    auto retire = [&]() {
+        a.hits[slot] = make_float4(closest_t, __int_as_float(closest_idx),
+                                   __uint_as_float(closest_prim | (overflow ? 0x80000000u : 0u)), __uint_as_float(seed));
+        if (a.tap && pix < a.n_pixels) {
+            a.tap_tri[pix] = closest_idx;
+            a.tap_prim[pix] = closest_idx >= 0 ? (int32_t)closest_prim : -1;
+            a.tap_t[pix] = closest_t;
+        }
+        st = ST_DONE;
+    };
+    // between primitives: next candidate of this chunk, else the next chunk, else the ray is done
+    auto advance = [&]() {
+        if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) {
+            st = ST_PRIM;
+        } else {
+            cb += 128u;
+            if (cb < sc.n_prims) st = ST_SCAN;
+            else retire();
+        }
+    };
+    // the traversal of primitive p ended: shader.wgsl:610-614
+    auto finish = [&]() {
+        if (best_i >= 0) {
+            closest_t = best_t / scale;
+            closest_idx = best_i;
+            closest_prim = p;
+        }
+        advance();
+    };
+    auto enter = [&](uint32_t first, uint32_t count) {
+        cur_first = first;
+        cur_count = count;
+        st = count > 0u ? ST_LEAF : ST_INNER;
+        if (COUNT && count > 0u) c_leaf++;
+    };
+    auto pop_or_finish = [&]() {
+        if (sp == 0u) {
+            finish();
+        } else {
+            const uint32_t nd = stack[(--sp) * RT_WAVE];
+            const float4 q = ld16(nodes, nd * 32u + 16u);
+            enter(__float_as_uint(q.z), __float_as_uint(q.w));
+        }
+    };
 
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.cursor, RT_WAVE);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        const uint32_t slot = base + lane;
-        float4 s0 = make_float4(0, 0, 0, 1), s1 = make_float4(0, 0, 0, __uint_as_float(RT_NO_PIXEL));
-        if (slot < n) { s0 = a.in.s0[slot]; s1 = a.in.s1[slot]; }
-        const uint32_t pix = __float_as_uint(s1.w);
-        const bool live = slot < n && pix != RT_NO_PIXEL;
-        const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
-        uint32_t seed = __float_as_uint(s1.z);
-        int32_t closest_idx = -1;
-        float closest_t = 99999999.0f;
-        uint32_t closest_prim = 0;
-        bool overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
-        if (COUNT && live) c_rays++;
+        const uint32_t n_prim = (uint32_t)__popcll(__ballot(st == ST_PRIM));
+        const uint32_t n_inner = (uint32_t)__popcll(__ballot(st == ST_INNER));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(st == ST_LEAF));
+        const unsigned long long scan_m = __ballot(st == ST_SCAN);
+        const unsigned long long done_m = __ballot(st == ST_DONE);
+        const uint32_t n_scan = (uint32_t)__popcll(scan_m), n_done = (uint32_t)__popcll(done_m);
+        const uint32_t n_trav = n_prim + n_inner + n_leaf;
 
-        for (uint32_t chunk = 0; chunk < sc.n_prims; chunk += 128u) {
-            // ---- candidate scan (wave-uniform over primitives)
-            uint32_t mask[4];
-            {
-                // A zero direction component makes 1/d infinite and b * inf - o * inf a NaN that would
-                // silently drop that axis' bound on one side only; a huge finite reciprocal keeps the
-                // sign logic of the slab test intact (the reference's own tests keep the true 1/d).
-                const f3 r = rcp3(d);
-                const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
-                const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    uint32_t m = 0;
-                    const uint32_t p0 = chunk + 32u * w;
-                    const uint32_t pe = min(p0 + 32u, sc.n_prims);
-                    for (uint32_t p = p0; p < pe; p++) {
-                        const rt_cfloat_p wb = (rt_cfloat_p)(sc.primx[p].wbox);
-                        const float b[6] = {wb[0], wb[1], wb[2], wb[3], wb[4], wb[5]};
-                        m |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (p - p0);
-                    }
-                    mask[w] = live ? m : 0u;
+        // ---- refill: hand reserved queue slots to the lanes that wait for a ray
+        if (n_done != 0u && !drained && (n_done >= RT_REFILL_LANES || n_trav + n_scan == 0u)) {
+            if (run_next == run_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.cursor, RT_WAVE);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) {
+                    drained = true;
+                } else {
+                    run_next = base;
+                    run_end = min(base + RT_WAVE, n);
+                    if (COUNT) r_batch++;
                 }
             }
-
-            // ---- per-lane traversal state
-            uint32_t st = ST_PRIM;
-            uint32_t p = 0, cur_first = 0, cur_count = 0, sp = 0, mode = 0;
-            f3 lo = o, ld = d, lidir = d;
-            float scale = 1.0f, best_t = 0.0f;
-            int32_t best_i = -1;
-
-            // the traversal of primitive p ended: shader.wgsl:610-614
-            auto finish = [&]() {
-                if (best_i >= 0) {
-                    closest_t = best_t / scale;
-                    closest_idx = best_i;
-                    closest_prim = p;
-                }
-                st = ST_PRIM;
-            };
-            auto enter = [&](uint32_t first, uint32_t count) {
-                cur_first = first;
-                cur_count = count;
-                st = count > 0u ? ST_LEAF : ST_INNER;
-                if (COUNT && count > 0u) c_leaf++;
-            };
-            auto pop_or_finish = [&]() {
-                if (sp == 0u) {
-                    finish();
-                } else {
-                    const uint32_t nd = stack[(--sp) * RT_WAVE];
-                    const float4 q = ld16(nodes, nd * 32u + 16u);
-                    enter(__float_as_uint(q.z), __float_as_uint(q.w));
-                }
-            };
-
-            for (;;) {
-                const bool has_prim = (mask[0] | mask[1] | mask[2] | mask[3]) != 0u;
-                const uint32_t n_prim = (uint32_t)__popcll(__ballot(st == ST_PRIM && has_prim));
-                const uint32_t n_inner = (uint32_t)__popcll(__ballot(st == ST_INNER));
-                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(st == ST_LEAF));
-                if ((n_prim | n_inner | n_leaf) == 0u) break;
-
-                if (n_inner >= n_prim && n_inner >= n_leaf) {
-#pragma unroll 1
-                    for (int burst = 0; burst < RT_INNER_BURST; burst++) {
-                        if (st == ST_INNER) {
-                            if (COUNT) c_inner++;
-                            const uint32_t off = cur_first * 32u; // siblings: one aligned 64-byte fetch
-                            const float4 l0 = ld16(nodes, off), l1 = ld16(nodes, off + 16u);
-                            const float4 q0 = ld16(nodes, off + 32u), q1 = ld16(nodes, off + 48u);
-                            const float left = hit_aabb_s(lo, lidir, l0, l1);
-                            const float right = hit_aabb_s(lo, lidir, q0, q1);
-                            const bool lmiss = (left < -0.5f || left > best_t);
-                            const bool rmiss = (right < -0.5f || right > best_t);
-                            if (lmiss && rmiss) {
-                                pop_or_finish();
-                            } else {
-                                const bool go_left = rmiss ? true : (lmiss ? false : left < right);
-                                if (!lmiss && !rmiss) {
-                                    if (sp < depth) { stack[sp * RT_WAVE] = go_left ? cur_first + 1u : cur_first; sp++; }
-                                    else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
-                                }
-                                enter(__float_as_uint(go_left ? l1.z : q1.z), __float_as_uint(go_left ? l1.w : q1.w));
-                            }
-                        }
-                        if (__ballot(st == ST_INNER) == 0ull) break;
-                    }
-                } else if (n_leaf >= n_prim) {
-                    if (st == ST_LEAF) {
-                        const uint32_t off = cur_first * 48u;
-                        const float4 a0 = ld16(tris, off), a1 = ld16(tris, off + 16u), a2 = ld16(tris, off + 32u);
-                        if (COUNT) c_tri++;
-                        float u, v;
-                        const float t = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
-                        if (t >= 0.0f && t < best_t) {
-                            bool accept = true;
-                            if (mode != 0u) { // shader.wgsl:464-487
-                                if (COUNT) c_alpha++;
-                                const PrimX& px = sc.primx[p];
-                                const float b0 = (1.0f - u) - v;
-                                const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
-                                const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)cur_first);
-                                const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
-                                float tcx = 0.0f, tcy = 0.0f;
-                                tcx += b0 * t0.x; tcy += b0 * t0.y;
-                                tcx += u * t1.x;  tcy += u * t1.y;
-                                tcx += v * t2.x;  tcy += v * t2.y;
-                                float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
-                                const uint32_t asize = px.albedo_size;
-                                if (asize != 0u) {
-                                    if (COUNT) c_texel++;
-                                    alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
-                                }
-                                if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
-                                else accept = !(rnd(seed) > alpha);
-                            }
-                            if (accept) { best_i = (int32_t)cur_first; best_t = t; }
-                        }
-                        cur_first++;
-                        cur_count--;
-                        if (cur_count == 0u) pop_or_finish();
-                    }
-                } else {
-                    if (st == ST_PRIM && has_prim) {
-                        // next candidate in index order
-                        uint32_t k;
-                        if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
-                        else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
-                        else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
-                        else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
-                        p = chunk + k;
-                        const uint32_t poff = p * (uint32_t)sizeof(PrimX);
-                        const float4 m0 = ld16(sc.primx, poff), m1 = ld16(sc.primx, poff + 16u), m2 = ld16(sc.primx, poff + 32u),
-                                     m3 = ld16(sc.primx, poff + 48u);
-                        const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
-                        // transform_ray + scale factor, shader.wgsl:604-607
-                        const f3 td = xform_dir(d, inv);
-                        scale = length(td);
-                        ld = td / scale;
-                        lo = xform_pos(o, inv);
-                        lidir = rcp3(ld);
-                        const uint32_t root = __float_as_uint(m3.x);
-                        mode = __float_as_uint(m3.y) & 3u;
-                        const float4 r0 = ld16(nodes, root * 32u), r1 = ld16(nodes, root * 32u + 16u);
-                        if (COUNT) c_prims++;
-                        if (!(hit_aabb_s(lo, lidir, r0, r1) < -0.5f)) { // shader.wgsl:448
-                            best_t = closest_t * scale;
-                            best_i = -1;
-                            sp = 0;
-                            enter(__float_as_uint(r1.z), __float_as_uint(r1.w));
-                        }
+            if (!drained) {
+                const uint32_t avail = run_end - run_next;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_m, 0u));
+                if (st == ST_DONE && rank < avail) {
+                    slot = run_next + rank;
+                    const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+                    pix = __float_as_uint(s1.w);
+                    if (pix != RT_NO_PIXEL) { // slots outside the image carry no ray
+                        o = F3(s0.x, s0.y, s0.z);
+                        d = F3(s0.w, s1.x, s1.y);
+                        seed = __float_as_uint(s1.z);
+                        closest_idx = -1;
+                        closest_t = 99999999.0f;
+                        closest_prim = 0;
+                        overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
+                        cb = 0;
+                        st = ST_SCAN;
+                        if (COUNT) c_rays++;
                     }
                 }
+                run_next += min(avail, n_done);
             }
+            continue;
         }
 
-        if (slot < n) {
-            a.hits[slot] = make_float4(closest_t, __int_as_float(closest_idx),
-                                       __uint_as_float(closest_prim | (overflow ? 0x80000000u : 0u)),
-                                       __uint_as_float(seed));
-            if (a.tap && live) {
-                a.tap_tri[pix] = closest_idx;
-                a.tap_prim[pix] = closest_idx >= 0 ? (int32_t)closest_prim : -1;
-                a.tap_t[pix] = closest_t;
+        // ---- candidate scan for the lanes that wait for a mask (wave-uniform over primitives)
+        if (n_scan != 0u && (n_scan >= RT_SCAN_LANES || n_trav == 0u)) {
+            // the chunk the first waiting lane wants; lanes that want another chunk wait for a later scan
+            const uint32_t c0 = __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(scan_m));
+            const bool mine = st == ST_SCAN && cb == c0;
+            // A zero direction component makes 1/d infinite and b * inf - o * inf a NaN that would
+            // silently drop that axis' bound on one side only; a huge finite reciprocal keeps the
+            // sign logic of the slab test intact (the reference's own tests keep the true 1/d).
+            const f3 r = rcp3(d);
+            const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
+            const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+            uint32_t m[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t mw = 0;
+                const uint32_t p0 = c0 + 32u * w;
+                const uint32_t pe = min(p0 + 32u, sc.n_prims);
+                for (uint32_t q = p0; q < pe; q++) {
+                    const rt_cfloat_p wb = (rt_cfloat_p)(sc.primx[q].wbox);
+                    const float b[6] = {wb[0], wb[1], wb[2], wb[3], wb[4], wb[5]};
+                    mw |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (q - p0);
+                }
+                m[w] = mw;
+            }
+            if (mine) {
+                mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];
+                cb = c0;
+                if ((m[0] | m[1] | m[2] | m[3]) != 0u) {
+                    st = ST_PRIM;
+                } else {
+                    cb += 128u;
+                    if (cb >= sc.n_prims) retire();
+                }
+            }
+            continue;
+        }
+
+        if (n_trav == 0u) break; // every lane is done or idle and the queue is drained
+
+        if (n_inner >= n_prim && n_inner >= n_leaf) {
+#pragma unroll 1
+            for (int burst = 0; burst < RT_INNER_BURST; burst++) {
+                if (COUNT) r_inner++;
+                if (st == ST_INNER) {
+                    if (COUNT) c_inner++;
+                    const uint32_t off = cur_first * 32u; // siblings: one aligned 64-byte fetch
+                    const float4 l0 = ld16(nodes, off), l1 = ld16(nodes, off + 16u);
+                    const float4 q0 = ld16(nodes, off + 32u), q1 = ld16(nodes, off + 48u);
+                    const float left = hit_aabb_s(lo, lidir, l0, l1);
+                    const float right = hit_aabb_s(lo, lidir, q0, q1);
+                    const bool lmiss = (left < -0.5f || left > best_t);
+                    const bool rmiss = (right < -0.5f || right > best_t);
+                    if (lmiss && rmiss) {
+                        pop_or_finish();
+                    } else {
+                        const bool go_left = rmiss ? true : (lmiss ? false : left < right);
+                        if (!lmiss && !rmiss) {
+                            if (sp < depth) { stack[sp * RT_WAVE] = go_left ? cur_first + 1u : cur_first; sp++; }
+                            else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
+                        }
+                        enter(__float_as_uint(go_left ? l1.z : q1.z), __float_as_uint(go_left ? l1.w : q1.w));
+                    }
+                }
+                if (__ballot(st == ST_INNER) == 0ull) break;
+            }
+        } else if (n_leaf >= n_prim) {
+            if (COUNT) r_leaf++;
+            if (st == ST_LEAF) {
+                const uint32_t off = cur_first * 48u;
+                const float4 a0 = ld16(tris, off), a1 = ld16(tris, off + 16u), a2 = ld16(tris, off + 32u);
+                if (COUNT) c_tri++;
+                float u, v;
+                const float t = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
+                if (t >= 0.0f && t < best_t) {
+                    bool accept = true;
+                    if (mode != 0u) { // shader.wgsl:464-487
+                        if (COUNT) c_alpha++;
+                        const PrimX& px = sc.primx[p];
+                        const float b0 = (1.0f - u) - v;
+                        const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
+                        const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)cur_first);
+                        const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
+                        float tcx = 0.0f, tcy = 0.0f;
+                        tcx += b0 * t0.x; tcy += b0 * t0.y;
+                        tcx += u * t1.x;  tcy += u * t1.y;
+                        tcx += v * t2.x;  tcy += v * t2.y;
+                        float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
+                        const uint32_t asize = px.albedo_size;
+                        if (asize != 0u) {
+                            if (COUNT) c_texel++;
+                            alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
+                        }
+                        if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
+                        else accept = !(rnd(seed) > alpha);
+                    }
+                    if (accept) { best_i = (int32_t)cur_first; best_t = t; }
+                }
+                cur_first++;
+                cur_count--;
+                if (cur_count == 0u) pop_or_finish();
+            }
+        } else {
+            if (COUNT) r_prim++;
+            if (st == ST_PRIM) {
+                // next candidate in index order
+                uint32_t k;
+                if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
+                else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
+                else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
+                else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
+                p = cb + k;
+                const uint32_t poff = p * (uint32_t)sizeof(PrimX);
+                const float4 m0 = ld16(sc.primx, poff), m1 = ld16(sc.primx, poff + 16u), m2 = ld16(sc.primx, poff + 32u),
+                             m3 = ld16(sc.primx, poff + 48u);
+                const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
+                // transform_ray + scale factor, shader.wgsl:604-607
+                const f3 td = xform_dir(d, inv);
+                scale = length(td);
+                ld = td / scale;
+                lo = xform_pos(o, inv);
+                lidir = rcp3(ld);
+                const uint32_t root = __float_as_uint(m3.x);
+                mode = __float_as_uint(m3.y) & 3u;
+                const float4 r0 = ld16(nodes, root * 32u), r1 = ld16(nodes, root * 32u + 16u);
+                if (COUNT) c_prims++;
+                if (!(hit_aabb_s(lo, lidir, r0, r1) < -0.5f)) { // shader.wgsl:448
+                    best_t = closest_t * scale;
+                    best_i = -1;
+                    sp = 0;
+                    enter(__float_as_uint(r1.z), __float_as_uint(r1.w));
+                } else {
+                    advance();
+                }
             }
         }
     }
@@ -417,6 +506,12 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
         for (int k = 0; k < 8; k++) {
             const unsigned long long sum = wave_sum(v[k]);
             if (lane == 0 && sum) atomicAdd(&a.counters[idx[k]], sum);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters[C_ROUNDS_PRIM], r_prim);
+            atomicAdd(&a.counters[C_ROUNDS_INNER], r_inner);
+            atomicAdd(&a.counters[C_ROUNDS_LEAF], r_leaf);
+            atomicAdd(&a.counters[C_BATCHES], r_batch);
         }
     }
 }
@@ -430,11 +525,11 @@ struct ShadeArgs {
     const float4* hits;
     const uint32_t* count_in;
     uint32_t* count_out;
-    float4*   accum;
-    uint32_t* tap_seed;     // null unless taps are on for this frame
+    float4*   partial;      // one accumulation slot per (frame slot, pixel): written once, by the path's end
+    uint32_t* tap_seed;     // null unless taps are on for this launch
     float     term_prob;
     uint32_t  last_bounce;  // 1: survivors of this bounce end here (loop bound, shader.wgsl:898)
-    uint32_t  overwrite;    // reject_hist == 1 (shader.wgsl:947-951)
+    uint32_t  n_pixels;
     uint32_t  pad;
     unsigned long long* counters;
 };
@@ -601,15 +696,10 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
                 o3 = make_float4(lit.x, lit.y, lit.z, 0.0f);
             }
 
-            if (!survive) { // the path ends: shader.wgsl:941-951
+            if (!survive) { // the path ends: shader.wgsl:941-946; k_accumulate applies 947-951
                 if (overflow) lit = F3(1.0f, 1.0f, 0.0f);
-                if (a.overwrite) {
-                    a.accum[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
-                } else {
-                    const float4 p = a.accum[pix];
-                    a.accum[pix] = make_float4(p.x + lit.x, p.y + lit.y, p.z + lit.z, p.w + 1.0f);
-                }
-                if (a.tap_seed) a.tap_seed[pix] = seed;
+                a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
+                if (a.tap_seed && pix < a.n_pixels) a.tap_seed[pix] = seed;
             }
         }
         const uint32_t dst = block_append(survive, a.count_out, scratch);
@@ -628,6 +718,26 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             if (s2) atomicAdd(&a.counters[C_KILL], s2);
             if (s3) atomicAdd(&a.counters[C_TEXEL], s3);
         }
+    }
+}
+
+// ------------------------------------------------------------------ accumulate
+
+// shader.wgsl:947-951 for the frames of one launch group, in frame order:
+// screen = reject_hist ? (L, 1) : screen + (L, 1).  Adding the frames one after the other keeps
+// the float sum bit-identical to rendering them one launch at a time.
+__global__ __launch_bounds__(256) void k_accumulate(float4* accum, const float4* partial, uint32_t n_pixels, uint32_t n_frames, uint32_t overwrite) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += stride) {
+        float4 acc;
+        uint32_t f = 0;
+        if (overwrite) { acc = partial[i]; f = 1; }
+        else acc = accum[i];
+        for (; f < n_frames; f++) {
+            const float4 p = partial[(size_t)f * n_pixels + i];
+            acc = make_float4(acc.x + p.x, acc.y + p.y, acc.z + p.z, acc.w + p.w);
+        }
+        accum[i] = acc;
     }
 }
 

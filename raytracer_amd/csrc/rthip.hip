@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -58,6 +59,8 @@ struct rthip_ctx {
     bool      accum_is_bound = false;
     float4*   queue_mem = nullptr;   // 2 queues x 4 streams x n_pixels
     float4*   hits = nullptr;
+    float4*   partial = nullptr;    // frames_cap x n_pixels accumulation slots
+    uint32_t  frames_cap = 0;       // frames one launch group can hold
     uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors
     int32_t*  tap_tri = nullptr;
     int32_t*  tap_prim = nullptr;
@@ -118,7 +121,8 @@ void free_scene(rthip_ctx* c) {
 }
 
 void free_frame_buffers(rthip_ctx* c) {
-    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits);
+    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial);
+    c->frames_cap = 0;
     free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
     c->buf_pixels = 0;
     if (!c->accum_is_bound) c->accum = nullptr;
@@ -155,26 +159,53 @@ bool invert4(const double m[16], double out[16]) {
 struct HostNode { float aabb[6]; uint32_t first, count; };
 struct HostTri { float v[3][4]; };
 
-int ensure_frame_buffers(rthip_ctx* c) {
+// Frames (samples per pixel) that travel through the stages together.  More frames in flight keep
+// the thin late bounces wide enough to fill the chip; the cost is queue memory (144 bytes per
+// path).  RTHIP_FRAMES_IN_FLIGHT overrides the default.
+uint32_t frames_in_flight_limit(const rthip_ctx* c) {
+    uint32_t want = 8;
+    if (const char* e = std::getenv("RTHIP_FRAMES_IN_FLIGHT")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) want = (uint32_t)v;
+    }
+    const uint64_t slots = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
+    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * 160ull > (8ull << 30))) want--;
+    return want;
+}
+
+int ensure_frame_buffers(rthip_ctx* c, uint32_t frames) {
     const uint64_t n = c->n_pixels;
-    if (c->buf_pixels == n && c->queue_mem) return RTHIP_OK;
+    if (c->buf_pixels == n && c->queue_mem && c->frames_cap >= frames) return RTHIP_OK;
+    const bool keep_accum = c->buf_pixels == n && c->accum_own != nullptr;
+    float4* kept = nullptr;
+    if (keep_accum) { kept = c->accum_own; c->accum_own = nullptr; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_frame_buffers(c);
     // queue slots are handed out per 8x8 pixel tile, so edge tiles pad the capacity
-    const uint64_t cap = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
+    const uint64_t per_frame = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
+    const uint64_t cap = per_frame * frames;
     c->queue_cap = cap;
     HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * cap));
     HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * cap));
+    HIP_TRY(c, hipMalloc((void**)&c->partial, sizeof(float4) * n * frames));
     HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
     HIP_TRY(c, hipMalloc((void**)&c->tap_prim, sizeof(int32_t) * n));
     HIP_TRY(c, hipMalloc((void**)&c->tap_t, sizeof(float) * n));
     HIP_TRY(c, hipMalloc((void**)&c->tap_seed, sizeof(uint32_t) * n));
     c->taps_valid = false;
     if (!c->accum_is_bound) {
-        HIP_TRY(c, hipMalloc((void**)&c->accum_own, sizeof(float4) * n));
-        HIP_TRY(c, hipMemsetAsync(c->accum_own, 0, sizeof(float4) * n, c->stream));
+        if (kept) {
+            c->accum_own = kept;
+        } else {
+            HIP_TRY(c, hipMalloc((void**)&c->accum_own, sizeof(float4) * n));
+            HIP_TRY(c, hipMemsetAsync(c->accum_own, 0, sizeof(float4) * n, c->stream));
+        }
         c->accum = c->accum_own;
+    } else if (kept) {
+        (void)hipFree(kept);
     }
     c->buf_pixels = n;
+    c->frames_cap = frames;
     return RTHIP_OK;
 }
 
@@ -502,13 +533,15 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     if (n_frames == 0) return RTHIP_OK;
 
     DeviceGuard g(c->device);
-    int rc = ensure_frame_buffers(c);
+    const uint32_t group = std::min<uint32_t>(n_frames, frames_in_flight_limit(c));
+    int rc = ensure_frame_buffers(c, group);
     if (rc != RTHIP_OK) return rc;
     if (c->accum_is_bound && c->accum_bound_pixels != c->n_pixels) return fail(c, RTHIP_ERR_STATE, "render: bound accumulator size mismatch");
 
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
     const bool taps = (P.flags & RTHIP_FLAG_TAPS) != 0;
     const bool timing = (P.flags & RTHIP_FLAG_TIMING) != 0;
+
     // camera constants of camera_ray (shader.wgsl:744-755), identical for every pixel
     float cam[12];
     std::memcpy(cam, c->uniforms + 512, 48);
@@ -536,6 +569,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     ga.res_y = c->res_y;
     ga.tiles_x = (c->res_x + 7) / 8;
     ga.n_tiles = ga.tiles_x * ((c->res_y + 7) / 8);
+    ga.n_pixels = (uint32_t)c->n_pixels;
+    ga.frame_stride = frame_stride;
     ga.counters = count ? c->d_counters : nullptr;
 
     PathQueue q[2];
@@ -549,18 +584,24 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     int ext_blocks;
     if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, 64>, 256) : occupancy_blocks(k_extend<true, 24>, 256);
     else ext_blocks = deep ? occupancy_blocks(k_extend<false, 64>, 256) : occupancy_blocks(k_extend<false, 24>, 256);
-    const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (c->queue_cap + 255) / 256);
-    const uint32_t shade_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (c->queue_cap + 255) / 256);
-    const uint32_t gen_grid = (uint32_t)(((uint64_t)ga.n_tiles * 64 + 255) / 256);
+    if (const char* e = std::getenv("RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
+        const int v = std::atoi(e);
+        if (v > 0 && v <= 16) ext_blocks = v;
+    }
 
-    for (uint32_t f = 0; f < n_frames; f++) {
-        const uint32_t frame = first_frame + f * frame_stride;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += group) {
+        const uint32_t nf = std::min(group, n_frames - f0);
+        const uint64_t slots = (uint64_t)ga.n_tiles * 64 * nf;
+        const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (slots + 255) / 256);
+        const uint32_t shade_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (slots + 255) / 256);
+        const uint32_t gen_grid = (uint32_t)((slots + 255) / 256);
         const bool overwrite = (c->reject_hist == 1);
-        const bool tap_frame = taps && f == 0;
+        const bool tap_group = taps && f0 == 0;
         HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 128, c->stream));
         ga.out = q[0];
         ga.count_out = c->ctrl;
-        ga.frame = frame;
+        ga.first_frame = first_frame + f0 * frame_stride;
+        ga.n_frames = nf;
         {
             StageTimer t(c, timing, RTHIP_STAGE_GENERATE);
             hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(256), 0, c->stream, ga);
@@ -573,7 +614,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.count_in = c->ctrl + b;
             ea.cursor = c->ctrl + 64 + b;
             ea.stack_depth = P.stack_depth;
-            ea.tap = (tap_frame && b == 0) ? 1u : 0u;
+            ea.tap = (tap_group && b == 0) ? 1u : 0u;
+            ea.n_pixels = (uint32_t)c->n_pixels;
             ea.tap_tri = c->tap_tri;
             ea.tap_prim = c->tap_prim;
             ea.tap_t = c->tap_t;
@@ -595,11 +637,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             sa.hits = c->hits;
             sa.count_in = c->ctrl + b;
             sa.count_out = c->ctrl + b + 1;
-            sa.accum = c->accum;
-            sa.tap_seed = tap_frame ? c->tap_seed : nullptr;
+            sa.partial = c->partial;
+            sa.tap_seed = tap_group ? c->tap_seed : nullptr;
             sa.term_prob = P.term_prob;
             sa.last_bounce = (b + 1 == P.max_bounces) ? 1u : 0u;
-            sa.overwrite = overwrite ? 1u : 0u;
+            sa.n_pixels = (uint32_t)c->n_pixels;
             sa.counters = c->d_counters;
             {
                 StageTimer t(c, timing, RTHIP_STAGE_SHADE);
@@ -607,8 +649,14 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 else hipLaunchKernelGGL((k_shade<false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
             }
         }
+        {
+            StageTimer t(c, timing, RTHIP_STAGE_SHADE);
+            const uint32_t acc_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (c->n_pixels + 255) / 256);
+            hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
+                               (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
+        }
         c->reject_hist = 0; // main.rs:403
-        if (tap_frame) c->taps_valid = true;
+        if (tap_group) c->taps_valid = true;
     }
     HIP_TRY(c, hipGetLastError());
     return RTHIP_OK;
@@ -638,7 +686,7 @@ int rthip_accum_device_ptr(rthip_ctx* c, void** device_ptr, uint64_t* n_pixels) 
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!c->have_uniforms) return fail(c, RTHIP_ERR_STATE, "accum_device_ptr: no frame uniforms set");
     DeviceGuard g(c->device);
-    int rc = ensure_frame_buffers(c);
+    int rc = ensure_frame_buffers(c, std::max(c->frames_cap, 1u));
     if (rc != RTHIP_OK) return rc;
     if (device_ptr) *device_ptr = c->accum;
     if (n_pixels) *n_pixels = c->n_pixels;
@@ -660,7 +708,7 @@ int rthip_write_accum(rthip_ctx* c, const float* rgba, uint64_t n_pixels) {
     if (!rgba) return fail(c, RTHIP_ERR_INVALID, "write_accum: null input");
     if (!c->have_uniforms || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "write_accum: size mismatch");
     DeviceGuard g(c->device);
-    int rc = ensure_frame_buffers(c);
+    int rc = ensure_frame_buffers(c, std::max(c->frames_cap, 1u));
     if (rc != RTHIP_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->accum, rgba, sizeof(float4) * n_pixels, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -744,6 +792,8 @@ int rthip_get_counters(rthip_ctx* c, rthip_counters* out) {
     out->leaf_steps = h.v[C_LEAF]; out->tri_tests = h.v[C_TRI]; out->alpha_tests = h.v[C_ALPHA];
     out->texel_fetches = h.v[C_TEXEL]; out->shade_calls = h.v[C_SHADE]; out->misses = h.v[C_MISS];
     out->kills = h.v[C_KILL]; out->stack_overflows = h.v[C_OVERFLOW]; out->paths = h.v[C_PATHS];
+    out->rounds_prim = h.v[C_ROUNDS_PRIM]; out->rounds_inner = h.v[C_ROUNDS_INNER]; out->rounds_leaf = h.v[C_ROUNDS_LEAF];
+    out->batches = h.v[C_BATCHES];
     return RTHIP_OK;
 }
 

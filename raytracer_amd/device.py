@@ -53,7 +53,8 @@ class RenderParams(C.Structure):
 
 
 COUNTER_NAMES = ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests",
-                 "texel_fetches", "shade_calls", "misses", "kills", "stack_overflows", "paths")
+                 "texel_fetches", "shade_calls", "misses", "kills", "stack_overflows", "paths",
+                 "rounds_prim", "rounds_inner", "rounds_leaf", "batches")
 
 
 class CountersStruct(C.Structure):

@@ -53,6 +53,10 @@ pub struct rthip_counters {
     pub kills: u64,
     pub stack_overflows: u64,
     pub paths: u64,
+    pub rounds_prim: u64,
+    pub rounds_inner: u64,
+    pub rounds_leaf: u64,
+    pub batches: u64,
 }
 
 pub const RTHIP_FLAG_COUNTERS: u32 = 1;
