@@ -185,10 +185,10 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 // Lanes that must be waiting before the wave spends a refill (queue fetch) or a candidate scan
 // on them while other lanes still have traversal work.
 #ifndef RT_REFILL_LANES
-#define RT_REFILL_LANES 24
+#define RT_REFILL_LANES 32
 #endif
 #ifndef RT_SCAN_LANES
-#define RT_SCAN_LANES 24
+#define RT_SCAN_LANES 16
 #endif
 
 // Loads through the scalar cache: the address is wave-uniform and the data is never written by
@@ -215,6 +215,11 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
     return inside ? 0.0f : r;
 }
 
+// A traversal stack entry is the (first, count) pair of the postponed node packed into one
+// dword when it fits (count < 16, first < 2^27), so that a pop needs no memory access; otherwise
+// bit 31 is set and the low bits are the node's index, whose record the pop re-reads.
+#define RT_STACK_RELOAD 0x80000000u
+
 // trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
 //
 // Every lane runs exactly the reference's sequence of operations for its own ray -- primitives
@@ -234,9 +239,8 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // loads), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
 // bound the ray misses changes nothing the reference would compute.
 //
-// The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free); a
-// popped entry is a node index whose (first, count) words are re-read -- the reference does
-// not re-test the box of a popped node either.
+// The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free); the
+// reference does not re-test the box of a popped node either.
 template <bool COUNT, int CAP>
 __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     __shared__ uint32_t lds_stack[4 * CAP * RT_WAVE];
@@ -309,9 +313,14 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
         if (sp == 0u) {
             finish();
         } else {
-            const uint32_t nd = stack[(--sp) * RT_WAVE];
-            const float4 q = ld16(nodes, nd * 32u + 16u);
-            enter(__float_as_uint(q.z), __float_as_uint(q.w));
+            const uint32_t e = stack[(--sp) * RT_WAVE];
+            uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
+            if (e & RT_STACK_RELOAD) {
+                const float4 q = ld16(nodes, (e & 0x7FFFFFFFu) * 32u + 16u);
+                first = __float_as_uint(q.z);
+                count = __float_as_uint(q.w);
+            }
+            enter(first, count);
         }
     };
 
@@ -420,7 +429,12 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                     } else {
                         const bool go_left = rmiss ? true : (lmiss ? false : left < right);
                         if (!lmiss && !rmiss) {
-                            if (sp < depth) { stack[sp * RT_WAVE] = go_left ? cur_first + 1u : cur_first; sp++; }
+                            if (sp < depth) {
+                                const uint32_t ff = __float_as_uint(go_left ? q1.z : l1.z), fc = __float_as_uint(go_left ? q1.w : l1.w);
+                                const uint32_t nd = go_left ? cur_first + 1u : cur_first;
+                                stack[sp * RT_WAVE] = (fc < 16u && ff < 0x08000000u) ? (ff | (fc << 27)) : (RT_STACK_RELOAD | nd);
+                                sp++;
+                            }
                             else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
                         }
                         enter(__float_as_uint(go_left ? l1.z : q1.z), __float_as_uint(go_left ? l1.w : q1.w));

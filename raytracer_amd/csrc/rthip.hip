@@ -115,7 +115,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx);
+    free_dev(c->d_nodes); c->d_tris = nullptr; c->d_primx = nullptr; free_dev(c->d_exts);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -163,7 +163,7 @@ struct HostTri { float v[3][4]; };
 // the thin late bounces wide enough to fill the chip; the cost is queue memory (144 bytes per
 // path).  RTHIP_FRAMES_IN_FLIGHT overrides the default.
 uint32_t frames_in_flight_limit(const rthip_ctx* c) {
-    uint32_t want = 8;
+    uint32_t want = 16;
     if (const char* e = std::getenv("RTHIP_FRAMES_IN_FLIGHT")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 64) want = (uint32_t)v;
@@ -457,10 +457,25 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         if (bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    HIP_TRY(c, upload(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes));
-    HIP_TRY(c, upload(c->d_tris, dev_tris.data(), sizeof(float) * dev_tris.size()));
+    // nodes, triangles and primitive records share one arena (64-byte aligned parts, and 64 spare
+    // bytes so that a 64-byte fetch at the start of any record stays inside it)
+    auto align64 = [](uint64_t v) { return (v + 63ull) & ~63ull; };
+    const uint64_t tri_base = align64(sizeof(HostNode) * n_dev_nodes);
+    const uint64_t primx_base = align64(tri_base + sizeof(float) * dev_tris.size() + 16);
+    const uint64_t arena_bytes = align64(primx_base + sizeof(PrimX) * primx.size()) + 64;
+    if (arena_bytes >= 0xFFFFFFFFull)
+        return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: nodes + triangles of 4 GiB or more (%llu nodes, %llu triangles)",
+                    (unsigned long long)s->n_nodes, (unsigned long long)s->n_tris);
+    HIP_TRY(c, hipMalloc(&c->d_nodes, arena_bytes));
+    HIP_TRY(c, hipMemset(c->d_nodes, 0, arena_bytes));
+    HIP_TRY(c, hipMemcpy(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes, hipMemcpyHostToDevice));
+    if (!dev_tris.empty()) HIP_TRY(c, hipMemcpy(static_cast<char*>(c->d_nodes) + tri_base, dev_tris.data(), sizeof(float) * dev_tris.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(static_cast<char*>(c->d_nodes) + primx_base, primx.data(), sizeof(PrimX) * primx.size(), hipMemcpyHostToDevice));
+    c->d_tris = static_cast<char*>(c->d_nodes) + tri_base;     // views into the arena, not owned
+    c->d_primx = static_cast<char*>(c->d_nodes) + primx_base;
+    c->sc.tri_base = (uint32_t)tri_base;
+    c->sc.primx_base = (uint32_t)primx_base;
     HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
-    HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
     HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
     HIP_TRY(c, upload(c->d_texels, s->texels, sizeof(uint32_t) * s->n_texels));
     HIP_TRY(c, upload(c->d_env, s->env, sizeof(float) * 4 * (size_t)s->env_w * s->env_h));
@@ -650,7 +665,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             }
         }
         {
-            StageTimer t(c, timing, RTHIP_STAGE_SHADE);
+            StageTimer t(c, timing, RTHIP_STAGE_ACCUMULATE);
             const uint32_t acc_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (c->n_pixels + 255) / 256);
             hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
                                (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
 FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
-STAGES = ("generate", "extend", "shade", "resolve")
+STAGES = ("generate", "extend", "shade", "resolve", "accumulate")
 
 EXPORTS = (
     "rthip_device_count", "rthip_create", "rthip_destroy", "rthip_last_error", "rthip_set_stream",
@@ -62,7 +62,7 @@ class CountersStruct(C.Structure):
 
 
 class TimingStruct(C.Structure):
-    _fields_ = [("ms", C.c_double * 4), ("launches", C.c_uint64 * 4)]
+    _fields_ = [("ms", C.c_double * len(STAGES)), ("launches", C.c_uint64 * len(STAGES))]
 
 
 _lib = None
