@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=1)
     ap.add_argument("--terrain-n", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--first-frame", type=int, default=1, help="frame index of the first timed step (RNG key)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +128,7 @@ def main():
     p_plain = device.default_params(flags=device.FLAG_TIMING, **base)
     p_count = device.default_params(flags=device.FLAG_COUNTERS, **base)
     K, W = args.steps, args.warmup
-    first = rank + 1
+    first = args.first_frame + rank
     stride = world
 
     # warm-up (untimed)
@@ -205,7 +206,7 @@ def main():
                 "parallelism": f"spp-split x{n_gpus}" if n_gpus > 1 else "single",
             },
             "rays_per_step_per_gpu": round(rays_local / K, 1),
-            "stage_ms_per_step": {s: round(timing[s]["ms"] / K, 4) for s in ("generate", "extend", "shade", "accumulate")},
+            "stage_ms_per_step": {s: round(timing[s]["ms"] / K, 4) for s in ("generate", "extend", "shade", "sort", "accumulate")},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_extend",

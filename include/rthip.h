@@ -93,7 +93,8 @@ typedef struct {
 #define RTHIP_STAGE_SHADE    2
 #define RTHIP_STAGE_RESOLVE  3
 #define RTHIP_STAGE_ACCUMULATE 4 /* frame-ordered sum of the per-frame results into screen  */
-#define RTHIP_NUM_STAGES     5
+#define RTHIP_STAGE_SORT     5   /* coherence sort of secondary rays between bounces        */
+#define RTHIP_NUM_STAGES     6
 
 typedef struct {
     double   ms[RTHIP_NUM_STAGES];        /* summed kernel time per stage, HIP events       */

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,14 @@ struct EventPair {
 };
 
 } // namespace
+
+struct HostNode { float aabb[6]; uint32_t first, count; };
+struct HostTri { float v[3][4]; };
+
+// Outcome of trace() (shader.wgsl:598-627) for a ray whose direction is NaN in every component:
+// no box test fails (every comparison with NaN is false), so every node of every primitive is
+// visited, far child first, and no triangle test passes.  Only the stack depth matters.
+struct NanWalk { uint64_t inner = 0, leaf = 0, tri = 0, dropped = 0; };
 
 struct rthip_ctx {
     int         device = 0;
@@ -59,6 +68,12 @@ struct rthip_ctx {
     bool      accum_is_bound = false;
     float4*   queue_mem = nullptr;   // 2 queues x 4 streams x n_pixels
     float4*   hits = nullptr;
+    // host copy of the device tree, for the precomputed walk of a NaN-direction ray
+    std::vector<HostNode> host_nodes;
+    std::vector<uint32_t> prim_roots;
+    std::map<uint32_t, NanWalk> nan_walks; // by stack depth
+    uint32_t* sort_bins = nullptr;  // RT_SORT_BINS counters of the ray sort
+    float     scene_lo[3] = {0, 0, 0}, scene_inv_cell[3] = {0, 0, 0};
     float4*   partial = nullptr;    // frames_cap x n_pixels accumulation slots
     uint32_t  frames_cap = 0;       // frames one launch group can hold
     uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors
@@ -121,7 +136,7 @@ void free_scene(rthip_ctx* c) {
 }
 
 void free_frame_buffers(rthip_ctx* c) {
-    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial);
+    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->sort_bins);
     c->frames_cap = 0;
     free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
     c->buf_pixels = 0;
@@ -156,9 +171,6 @@ bool invert4(const double m[16], double out[16]) {
     return true;
 }
 
-struct HostNode { float aabb[6]; uint32_t first, count; };
-struct HostTri { float v[3][4]; };
-
 // Frames (samples per pixel) that travel through the stages together.  More frames in flight keep
 // the thin late bounces wide enough to fill the chip; the cost is queue memory (144 bytes per
 // path).  RTHIP_FRAMES_IN_FLIGHT overrides the default.
@@ -185,7 +197,8 @@ int ensure_frame_buffers(rthip_ctx* c, uint32_t frames) {
     const uint64_t per_frame = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
     const uint64_t cap = per_frame * frames;
     c->queue_cap = cap;
-    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * cap));
+    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 12 * cap));
+    HIP_TRY(c, hipMalloc((void**)&c->sort_bins, sizeof(uint32_t) * RT_SORT_BINS));
     HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * cap));
     HIP_TRY(c, hipMalloc((void**)&c->partial, sizeof(float4) * n * frames));
     HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
@@ -448,6 +461,22 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         std::memcpy(x.wbox, wb, sizeof wb);
     }
 
+    // scene bound for the ray sort: union of the finite primitive bounds
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (const PrimX& x : primx)
+            for (int r = 0; r < 3; r++)
+                if (std::isfinite(x.wbox[r]) && std::isfinite(x.wbox[3 + r])) {
+                    lo[r] = std::min(lo[r], (double)x.wbox[r]);
+                    hi[r] = std::max(hi[r], (double)x.wbox[3 + r]);
+                }
+        for (int r = 0; r < 3; r++) {
+            const bool ok = hi[r] > lo[r] && (hi[r] - lo[r]) < 1e30;
+            c->scene_lo[r] = ok ? (float)lo[r] : 0.0f;
+            c->scene_inv_cell[r] = ok ? (float)(8.0 / (hi[r] - lo[r])) : 0.0f;
+        }
+    }
+
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -494,6 +523,10 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->n_tris = s->n_tris;
     c->n_nodes = s->n_nodes;
     c->n_dev_nodes = n_dev_nodes;
+    c->prim_roots.resize(s->n_prims);
+    for (uint32_t p = 0; p < s->n_prims; p++) c->prim_roots[p] = primx[p].root;
+    c->host_nodes.swap(dev_nodes);
+    c->nan_walks.clear();
     c->node_index_map.swap(map);
     c->have_scene = true;
     c->reject_hist = 1;
@@ -529,6 +562,37 @@ void rthip_default_params(rthip_render_params* p) {
     p->stack_depth = 23;
     p->enable_sun = 0;
     p->flags = 0;
+}
+
+// Walks the device tree the way a NaN-direction ray does, with a stack of `depth` entries whose
+// overflowing pushes are dropped (shader.wgsl:306-313), and counts the steps.
+static const NanWalk& nan_walk(rthip_ctx* c, uint32_t depth) {
+    auto it = c->nan_walks.find(depth);
+    if (it != c->nan_walks.end()) return it->second;
+    NanWalk w;
+    std::vector<uint32_t> stack(depth ? depth : 1);
+    for (uint32_t root : c->prim_roots) {
+        uint32_t sp = 0;
+        uint32_t first = c->host_nodes[root].first, count = c->host_nodes[root].count;
+        for (;;) {
+            if (count > 0) { // leaf: every triangle is tested, none is hit
+                w.leaf++;
+                w.tri += count;
+                if (sp == 0) break;
+                const HostNode& n = c->host_nodes[stack[--sp]];
+                first = n.first;
+                count = n.count;
+            } else {         // inner: both children "hit"; left < right is false, so right first
+                w.inner++;
+                if (sp < depth) stack[sp++] = first;
+                else w.dropped++;
+                const HostNode& n = c->host_nodes[first + 1];
+                first = n.first;
+                count = n.count;
+            }
+        }
+    }
+    return c->nan_walks.emplace(depth, w).first->second;
 }
 
 int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride, const rthip_render_params* params) {
@@ -588,13 +652,16 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     ga.frame_stride = frame_stride;
     ga.counters = count ? c->d_counters : nullptr;
 
-    PathQueue q[2];
-    for (int k = 0; k < 2; k++) {
+    PathQueue q[3];
+    for (int k = 0; k < 3; k++) {
         const uint64_t cap = c->queue_cap;
         float4* base = c->queue_mem + (size_t)k * 4 * cap;
         q[k].s0 = base; q[k].s1 = base + cap; q[k].s2 = base + 2 * cap; q[k].s3 = base + 3 * cap;
     }
 
+    bool sort_rays = true; // RTHIP_SORT_RAYS=0 turns the coherence sort of secondary rays off
+    if (const char* e = std::getenv("RTHIP_SORT_RAYS")) sort_rays = std::atoi(e) != 0;
+    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, P.stack_depth > 24 ? 64u : 24u));
     const bool deep = P.stack_depth > 24;
     int ext_blocks;
     if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, 64>, 256) : occupancy_blocks(k_extend<true, 24>, 256);
@@ -614,6 +681,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const bool tap_group = taps && f0 == 0;
         HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 128, c->stream));
         ga.out = q[0];
+        int qi = 0; // queue that holds the rays of the current bounce
         ga.count_out = c->ctrl;
         ga.first_frame = first_frame + f0 * frame_stride;
         ga.n_frames = nf;
@@ -624,7 +692,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         for (uint32_t b = 0; b < P.max_bounces; b++) {
             ExtArgs ea{};
             ea.sc = c->sc;
-            ea.in = q[b & 1];
+            ea.in = q[qi];
             ea.hits = c->hits;
             ea.count_in = c->ctrl + b;
             ea.cursor = c->ctrl + 64 + b;
@@ -635,6 +703,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.tap_prim = c->tap_prim;
             ea.tap_t = c->tap_t;
             ea.counters = c->d_counters;
+            ea.nan_inner = nanw.inner;
+            ea.nan_leaf = nanw.leaf;
+            ea.nan_tri = nanw.tri;
+            ea.nan_dropped = nanw.dropped;
+            ea.nan_overflow = nanw.dropped ? 1u : 0u;
             {
                 StageTimer t(c, timing, RTHIP_STAGE_EXTEND);
                 if (count) {
@@ -647,8 +720,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             }
             ShadeArgs sa{};
             sa.sc = c->sc;
-            sa.in = q[b & 1];
-            sa.out = q[(b + 1) & 1];
+            const int qo = (qi + 1) % 3, qs = (qi + 2) % 3;
+            sa.in = q[qi];
+            sa.out = q[qo];
             sa.hits = c->hits;
             sa.count_in = c->ctrl + b;
             sa.count_out = c->ctrl + b + 1;
@@ -662,6 +736,22 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 StageTimer t(c, timing, RTHIP_STAGE_SHADE);
                 if (count) hipLaunchKernelGGL((k_shade<true>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
                 else hipLaunchKernelGGL((k_shade<false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+            }
+            qi = qo;
+            if (sort_rays && b + 1 < P.max_bounces) {
+                StageTimer t(c, timing, RTHIP_STAGE_SORT);
+                SortArgs so{};
+                so.in = q[qo];
+                so.out = q[qs];
+                so.count = c->ctrl + b + 1;
+                so.bins = c->sort_bins;
+                std::memcpy(so.lo, c->scene_lo, sizeof so.lo);
+                std::memcpy(so.inv_cell, c->scene_inv_cell, sizeof so.inv_cell);
+                (void)hipMemsetAsync(c->sort_bins, 0, sizeof(uint32_t) * RT_SORT_BINS, c->stream);
+                hipLaunchKernelGGL(k_sort_count, dim3(shade_grid), dim3(256), 0, c->stream, so);
+                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, c->sort_bins);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(shade_grid), dim3(256), 0, c->stream, so);
+                qi = qs;
             }
         }
         {

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Vector-memory pipeline counters of the benchmark (texture addresser, L1, address translation).
+# Usage (on the GPU box, from the repo root): bash tools/prof_mem.sh <tag> [bench args...]
+set -u
+TAG=${1:-run}; shift || true
+OUT=gpurun_out/profmem_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ARGS="--steps 16 --warmup 0 --no-cpu-baseline $*"
+pass() { # name counters...
+  local name=$1; shift
+  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pmc pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
+}
+pass ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE && \
+pass tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TCP_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_DATA_STALLED_BY_TC_CYCLES_sum && \
+pass tcp3 TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum && \
+pass tcp4 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum
+python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+grep -A40 "k_extend<false" "$OUT/summary.txt" | head -60
