@@ -93,8 +93,7 @@ typedef struct {
 #define RTHIP_STAGE_SHADE    2
 #define RTHIP_STAGE_RESOLVE  3
 #define RTHIP_STAGE_ACCUMULATE 4 /* frame-ordered sum of the per-frame results into screen  */
-#define RTHIP_STAGE_SORT     5   /* coherence sort of secondary rays between bounces        */
-#define RTHIP_NUM_STAGES     6
+#define RTHIP_NUM_STAGES     5
 
 typedef struct {
     double   ms[RTHIP_NUM_STAGES];        /* summed kernel time per stage, HIP events       */
@@ -131,6 +130,12 @@ void rthip_default_params(rthip_render_params* p);
  * (main.rs:403).  Asynchronous: returns once the work is enqueued. */
 int rthip_render(rthip_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
                  const rthip_render_params* params);
+
+/* Allocates the per-frame work buffers for calls of up to n_frames frames now rather than inside
+ * the first rthip_render that needs them (frames travel through the stages in groups; a larger
+ * group needs larger queues).  Optional.  No counterpart upstream: wgpu buffers are created once
+ * per resolution (main.rs:79-94). */
+int rthip_reserve(rthip_ctx* ctx, uint32_t n_frames);
 
 /* Use caller-owned DEVICE memory (n_pixels * 4 floats, 16-byte aligned) as the accumulator,
  * e.g. a tensor that a collective library will reduce in place.  NULL returns to a

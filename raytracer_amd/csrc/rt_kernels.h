@@ -756,102 +756,6 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ sort
-
-// Secondary rays leave the shade stage in pixel order but point everywhere.  Before the next
-// extend launch they are grouped by where they start and which way they go: key = cell of the
-// ray origin in an 8x8x8 grid over the scene bound (9 bits) and the sign octant of the direction
-// (3 bits).  Rays of one wave then share most of their upper-tree traversal.  The order of the
-// queue has no effect on any result: every path carries its own accumulation slot.
-#define RT_SORT_BINS 4096u
-#define RT_SORT_CHUNK 4096u   // rays per block iteration of the scatter pass (16 per thread)
-
-struct SortArgs {
-    PathQueue in;
-    PathQueue out;
-    const uint32_t* count;
-    uint32_t* bins;        // RT_SORT_BINS counters: histogram, then running output offsets
-    float lo[3];           // scene bound minimum
-    float inv_cell[3];     // 8 / extent (0 disables the axis)
-};
-
-__device__ __forceinline__ uint32_t sort_key(const SortArgs& a, float4 s0, float4 s1) {
-    const uint32_t cx = min(f2u((s0.x - a.lo[0]) * a.inv_cell[0]), 7u);
-    const uint32_t cy = min(f2u((s0.y - a.lo[1]) * a.inv_cell[1]), 7u);
-    const uint32_t cz = min(f2u((s0.z - a.lo[2]) * a.inv_cell[2]), 7u);
-    const uint32_t oct = (s0.w < 0.0f ? 1u : 0u) | (s1.x < 0.0f ? 2u : 0u) | (s1.y < 0.0f ? 4u : 0u);
-    return (((cz * 8u + cy) * 8u + cx) << 3) | oct;
-}
-
-__global__ __launch_bounds__(256) void k_sort_count(SortArgs a) {
-    __shared__ uint32_t hist[RT_SORT_BINS];
-    for (uint32_t i = threadIdx.x; i < RT_SORT_BINS; i += 256u) hist[i] = 0u;
-    __syncthreads();
-    const uint32_t n = *a.count;
-    for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < n; slot += gridDim.x * 256u)
-        atomicAdd(&hist[sort_key(a, a.in.s0[slot], a.in.s1[slot])], 1u);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < RT_SORT_BINS; i += 256u)
-        if (hist[i]) atomicAdd(&a.bins[i], hist[i]);
-}
-
-// exclusive prefix sum of the RT_SORT_BINS counters, in place (one block of 1024 threads)
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* bins) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x;
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = bins[t * 4u + k]; sum += v[k]; }
-    part[t] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024u; o <<= 1) {
-        const uint32_t add = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - sum;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { bins[t * 4u + k] = run; run += v[k]; }
-}
-
-__global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a) {
-    __shared__ uint32_t cnt[RT_SORT_BINS];   // rays of this chunk per bin, then the bin's output base
-    const uint32_t n = *a.count;
-    for (uint32_t base = blockIdx.x * RT_SORT_CHUNK; base < n; base += gridDim.x * RT_SORT_CHUNK) {
-        for (uint32_t i = threadIdx.x; i < RT_SORT_BINS; i += 256u) cnt[i] = 0u;
-        __syncthreads();
-        uint32_t kr[RT_SORT_CHUNK / 256u]; // key | rank within the chunk's bin << 12
-#pragma unroll
-        for (uint32_t k = 0; k < RT_SORT_CHUNK / 256u; k++) {
-            const uint32_t slot = base + k * 256u + threadIdx.x;
-            kr[k] = 0xFFFFFFFFu;
-            if (slot < n) {
-                const uint32_t key = sort_key(a, a.in.s0[slot], a.in.s1[slot]);
-                kr[k] = key | (atomicAdd(&cnt[key], 1u) << 12);
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < RT_SORT_BINS; i += 256u) {
-            const uint32_t c = cnt[i];
-            if (c) cnt[i] = atomicAdd(&a.bins[i], c);
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < RT_SORT_CHUNK / 256u; k++) {
-            const uint32_t slot = base + k * 256u + threadIdx.x;
-            if (kr[k] != 0xFFFFFFFFu) {
-                const uint32_t dst = cnt[kr[k] & 0xFFFu] + (kr[k] >> 12);
-                a.out.s0[dst] = a.in.s0[slot];
-                a.out.s1[dst] = a.in.s1[slot];
-                a.out.s2[dst] = a.in.s2[slot];
-                a.out.s3[dst] = a.in.s3[slot];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------ accumulate
 
 // shader.wgsl:947-951 for the frames of one launch group, in frame order:

@@ -72,8 +72,6 @@ struct rthip_ctx {
     std::vector<HostNode> host_nodes;
     std::vector<uint32_t> prim_roots;
     std::map<uint32_t, NanWalk> nan_walks; // by stack depth
-    uint32_t* sort_bins = nullptr;  // RT_SORT_BINS counters of the ray sort
-    float     scene_lo[3] = {0, 0, 0}, scene_inv_cell[3] = {0, 0, 0};
     float4*   partial = nullptr;    // frames_cap x n_pixels accumulation slots
     uint32_t  frames_cap = 0;       // frames one launch group can hold
     uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors
@@ -136,7 +134,7 @@ void free_scene(rthip_ctx* c) {
 }
 
 void free_frame_buffers(rthip_ctx* c) {
-    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->sort_bins);
+    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial);
     c->frames_cap = 0;
     free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
     c->buf_pixels = 0;
@@ -175,13 +173,13 @@ bool invert4(const double m[16], double out[16]) {
 // the thin late bounces wide enough to fill the chip; the cost is queue memory (144 bytes per
 // path).  RTHIP_FRAMES_IN_FLIGHT overrides the default.
 uint32_t frames_in_flight_limit(const rthip_ctx* c) {
-    uint32_t want = 16;
+    uint32_t want = 32;
     if (const char* e = std::getenv("RTHIP_FRAMES_IN_FLIGHT")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 64) want = (uint32_t)v;
     }
     const uint64_t slots = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
-    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * 160ull > (8ull << 30))) want--;
+    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * 160ull > (16ull << 30))) want--;
     return want;
 }
 
@@ -197,8 +195,7 @@ int ensure_frame_buffers(rthip_ctx* c, uint32_t frames) {
     const uint64_t per_frame = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
     const uint64_t cap = per_frame * frames;
     c->queue_cap = cap;
-    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 12 * cap));
-    HIP_TRY(c, hipMalloc((void**)&c->sort_bins, sizeof(uint32_t) * RT_SORT_BINS));
+    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * cap));
     HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * cap));
     HIP_TRY(c, hipMalloc((void**)&c->partial, sizeof(float4) * n * frames));
     HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
@@ -461,22 +458,6 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         std::memcpy(x.wbox, wb, sizeof wb);
     }
 
-    // scene bound for the ray sort: union of the finite primitive bounds
-    {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (const PrimX& x : primx)
-            for (int r = 0; r < 3; r++)
-                if (std::isfinite(x.wbox[r]) && std::isfinite(x.wbox[3 + r])) {
-                    lo[r] = std::min(lo[r], (double)x.wbox[r]);
-                    hi[r] = std::max(hi[r], (double)x.wbox[3 + r]);
-                }
-        for (int r = 0; r < 3; r++) {
-            const bool ok = hi[r] > lo[r] && (hi[r] - lo[r]) < 1e30;
-            c->scene_lo[r] = ok ? (float)lo[r] : 0.0f;
-            c->scene_inv_cell[r] = ok ? (float)(8.0 / (hi[r] - lo[r])) : 0.0f;
-        }
-    }
-
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -652,15 +633,13 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     ga.frame_stride = frame_stride;
     ga.counters = count ? c->d_counters : nullptr;
 
-    PathQueue q[3];
-    for (int k = 0; k < 3; k++) {
+    PathQueue q[2];
+    for (int k = 0; k < 2; k++) {
         const uint64_t cap = c->queue_cap;
         float4* base = c->queue_mem + (size_t)k * 4 * cap;
         q[k].s0 = base; q[k].s1 = base + cap; q[k].s2 = base + 2 * cap; q[k].s3 = base + 3 * cap;
     }
 
-    bool sort_rays = true; // RTHIP_SORT_RAYS=0 turns the coherence sort of secondary rays off
-    if (const char* e = std::getenv("RTHIP_SORT_RAYS")) sort_rays = std::atoi(e) != 0;
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, P.stack_depth > 24 ? 64u : 24u));
     const bool deep = P.stack_depth > 24;
     int ext_blocks;
@@ -681,7 +660,6 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const bool tap_group = taps && f0 == 0;
         HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 128, c->stream));
         ga.out = q[0];
-        int qi = 0; // queue that holds the rays of the current bounce
         ga.count_out = c->ctrl;
         ga.first_frame = first_frame + f0 * frame_stride;
         ga.n_frames = nf;
@@ -692,7 +670,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         for (uint32_t b = 0; b < P.max_bounces; b++) {
             ExtArgs ea{};
             ea.sc = c->sc;
-            ea.in = q[qi];
+            ea.in = q[b & 1];
             ea.hits = c->hits;
             ea.count_in = c->ctrl + b;
             ea.cursor = c->ctrl + 64 + b;
@@ -720,9 +698,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             }
             ShadeArgs sa{};
             sa.sc = c->sc;
-            const int qo = (qi + 1) % 3, qs = (qi + 2) % 3;
-            sa.in = q[qi];
-            sa.out = q[qo];
+            sa.in = q[b & 1];
+            sa.out = q[(b + 1) & 1];
             sa.hits = c->hits;
             sa.count_in = c->ctrl + b;
             sa.count_out = c->ctrl + b + 1;
@@ -737,22 +714,6 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 if (count) hipLaunchKernelGGL((k_shade<true>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
                 else hipLaunchKernelGGL((k_shade<false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
             }
-            qi = qo;
-            if (sort_rays && b + 1 < P.max_bounces) {
-                StageTimer t(c, timing, RTHIP_STAGE_SORT);
-                SortArgs so{};
-                so.in = q[qo];
-                so.out = q[qs];
-                so.count = c->ctrl + b + 1;
-                so.bins = c->sort_bins;
-                std::memcpy(so.lo, c->scene_lo, sizeof so.lo);
-                std::memcpy(so.inv_cell, c->scene_inv_cell, sizeof so.inv_cell);
-                (void)hipMemsetAsync(c->sort_bins, 0, sizeof(uint32_t) * RT_SORT_BINS, c->stream);
-                hipLaunchKernelGGL(k_sort_count, dim3(shade_grid), dim3(256), 0, c->stream, so);
-                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, c->sort_bins);
-                hipLaunchKernelGGL(k_sort_scatter, dim3(shade_grid), dim3(256), 0, c->stream, so);
-                qi = qs;
-            }
         }
         {
             StageTimer t(c, timing, RTHIP_STAGE_ACCUMULATE);
@@ -765,6 +726,14 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     }
     HIP_TRY(c, hipGetLastError());
     return RTHIP_OK;
+}
+
+int rthip_reserve(rthip_ctx* c, uint32_t n_frames) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_uniforms) return fail(c, RTHIP_ERR_STATE, "reserve: set_frame_uniforms first (the resolution sizes the buffers)");
+    if (n_frames == 0) return fail(c, RTHIP_ERR_INVALID, "reserve: n_frames = 0");
+    DeviceGuard g(c->device);
+    return ensure_frame_buffers(c, std::min<uint32_t>(n_frames, frames_in_flight_limit(c)));
 }
 
 int rthip_bind_accum(rthip_ctx* c, void* device_ptr, uint64_t n_pixels) {

@@ -15,11 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
 FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
-STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "sort")
+STAGES = ("generate", "extend", "shade", "resolve", "accumulate")
 
 EXPORTS = (
     "rthip_device_count", "rthip_create", "rthip_destroy", "rthip_last_error", "rthip_set_stream",
-    "rthip_upload_scene", "rthip_set_frame_uniforms", "rthip_default_params", "rthip_render",
+    "rthip_upload_scene", "rthip_set_frame_uniforms", "rthip_default_params", "rthip_render", "rthip_reserve",
     "rthip_bind_accum", "rthip_accum_device_ptr", "rthip_read_accum", "rthip_write_accum",
     "rthip_read_taps", "rthip_read_nodes_device_layout", "rthip_read_node_index_map",
     "rthip_read_tri_order", "rthip_read_tris_device_layout", "rthip_resolve",
@@ -86,6 +86,7 @@ def lib():
         l.rthip_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
         l.rthip_set_frame_uniforms.argtypes = [vp, vp]
         l.rthip_default_params.argtypes = [C.POINTER(RenderParams)]
+        l.rthip_reserve.argtypes = [vp, C.c_uint32]
         l.rthip_default_params.restype = None
         l.rthip_render.argtypes = [vp, u32, u32, u32, C.POINTER(RenderParams)]
         l.rthip_bind_accum.argtypes = [vp, vp, u64]
@@ -185,6 +186,10 @@ class Context:
     def render(self, first_frame=1, n_frames=1, frame_stride=1, params=None):
         p = params or default_params()
         self._check(lib().rthip_render(self._h, first_frame, n_frames, frame_stride, C.byref(p)))
+
+    def reserve(self, n_frames):
+        """Allocate the work buffers for calls of up to n_frames frames ahead of the first render."""
+        self._check(lib().rthip_reserve(self._h, int(n_frames)))
 
     def synchronize(self):
         self._check(lib().rthip_synchronize(self._h))

@@ -163,6 +163,33 @@ def test_parameter_variants_match_oracle(ctx, scenes, kw):
         assert got["counters"]["stack_overflows"] > 0
 
 
+@pytest.mark.parametrize("depth", [23, 3])
+def test_nan_direction_rays_match_oracle(ctx, scenes, depth):
+    """A NaN focus distance makes every camera ray's direction NaN.  The reference then fails no
+    box test and passes no triangle test: every node of every primitive is visited and the ray
+    misses.  The device takes that outcome from a host-side walk of the tree; hits, dropped pushes
+    and every step counter must equal the oracle's, which walks the tree ray by ray."""
+    s, a = scenes["materials"]
+    res = (16, 8)
+    params = device.default_params(max_bounces=2, stack_depth=depth)
+    params.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = np.ascontiguousarray(s.frame_uniforms(res, frame=1, reject_hist=1)).view(np.uint8).reshape(-1).copy()
+    u[540:544] = np.array([np.nan], np.float32).view(np.uint8)   # scene.camera.focus, shader.wgsl:769
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 2, 1, params)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    ref = orc.render(oracle_scene(a), u, oracle_params(params), 1, 2, 1, taps=True, n_threads=4)
+    assert np.all(ref["tri"] == -1) and np.array_equal(got["tri"], ref["tri"])
+    assert np.array_equal(got["seed"], ref["seed"])
+    for k in ("rays", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests", "stack_overflows", "misses"):
+        assert got["counters"][k] == ref["counters"][k], k
+    assert got["counters"]["prims_visited"] == ref["counters"]["root_tests"]   # no primitive is culled
+    assert (ref["counters"]["stack_overflows"] > 0) == (depth == 3)
+    np.testing.assert_array_equal(got["accum"], ref["accum"])
+
+
 def test_errors_are_reported_not_thrown(scenes):
     c = device.Context(0)
     with pytest.raises(device.RtHipError) as e:
