@@ -56,9 +56,6 @@ struct SceneDev {
     uint32_t          env_w, env_h;
     uint32_t          n_prims;
     uint32_t          pad;
-    // nodes, tris and primx are parts of one allocation that starts at `nodes`, so that the
-    // extend stage can address all three with one base and a 32-bit byte offset
-    uint32_t          tri_base, primx_base;
 };
 
 // Path state: four float4 streams per queue slot, so every access is a 16-byte-per-lane,

@@ -143,6 +143,7 @@ struct ExtArgs {
     SceneDev  sc;
     PathQueue in;
     float4*   hits;
+    uint32_t* spill;          // deep-stack levels beyond the LDS part (DEEP instantiation only)
     const uint32_t* count_in;
     uint32_t* cursor;
     uint32_t  stack_depth;
@@ -200,9 +201,10 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 // a kernel, which the constant address space tells the compiler.
 typedef const __attribute__((address_space(4))) float* rt_cfloat_p;
 
-// 16-byte load at base + 32-bit byte offset (SGPR base + VGPR offset addressing).
-__device__ __forceinline__ float4 ld16(const void* base, uint32_t byte_off) {
-    return *reinterpret_cast<const float4*>(static_cast<const char*>(base) + byte_off);
+// Address of a record given its position in 16-byte units (one 64-bit shift-add; the record's
+// further 16-byte pieces are immediate offsets of the loads).  32 bits of units span 64 GiB.
+__device__ __forceinline__ const float4* rec16(const void* base, uint32_t unit) {
+    return reinterpret_cast<const float4*>(static_cast<const char*>(base) + ((uint64_t)unit << 4));
 }
 
 // intersect_aabb (shader.wgsl:415-438) with the origin-inside test taken from the signs of the
@@ -224,6 +226,8 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // dword when it fits (count < 16, first < 2^27), so that a pop needs no memory access; otherwise
 // bit 31 is set and the low bits are the node's index, whose record the pop re-reads.
 #define RT_STACK_RELOAD 0x80000000u
+#define RT_LDS_LEVELS 24u
+#define RT_MAX_STACK 64u
 
 // trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
 //
@@ -244,15 +248,20 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // loads), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
 // bound the ray misses changes nothing the reference would compute.
 //
-// The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free); the
-// reference does not re-test the box of a popped node either.
-template <bool COUNT, int CAP>
+// The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free) for
+// the first RT_LDS_LEVELS entries; the DEEP instantiation (stack_depth above that, for trees of
+// tens of millions of triangles) continues in a global-memory column per thread, so that a deep
+// stack does not cost occupancy.  The reference does not re-test the box of a popped node either.
+template <bool COUNT, bool DEEP>
 __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
-    __shared__ uint32_t lds_stack[4 * CAP * RT_WAVE];
+    __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
     const uint32_t lane = lane_id();
-    uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (CAP * RT_WAVE) + lane;
+    uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (RT_LDS_LEVELS * RT_WAVE) + lane;
+    // levels RT_LDS_LEVELS.. of a deep stack: one global dword column per thread of the grid
+    uint32_t* spill = DEEP ? a.spill + (blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
+    const size_t spill_stride = (size_t)gridDim.x * blockDim.x;
     const uint32_t n = *a.count_in;
-    const uint32_t depth = a.stack_depth < (uint32_t)CAP ? a.stack_depth : (uint32_t)CAP;
+    const uint32_t depth = DEEP ? min(a.stack_depth, RT_MAX_STACK) : min(a.stack_depth, RT_LDS_LEVELS);
     const SceneDev& sc = a.sc;
     const void* const nodes = sc.nodes;
     const void* const tris = sc.tris;
@@ -318,10 +327,11 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
         if (sp == 0u) {
             finish();
         } else {
-            const uint32_t e = stack[(--sp) * RT_WAVE];
+            --sp;
+            const uint32_t e = (DEEP && sp >= RT_LDS_LEVELS) ? spill[(sp - RT_LDS_LEVELS) * spill_stride] : stack[sp * RT_WAVE];
             uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
             if (e & RT_STACK_RELOAD) {
-                const float4 q = ld16(nodes, (e & 0x7FFFFFFFu) * 32u + 16u);
+                const float4 q = rec16(nodes, (e & 0x7FFFFFFFu) * 2u)[1];
                 first = __float_as_uint(q.z);
                 count = __float_as_uint(q.w);
             }
@@ -438,9 +448,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 if (COUNT) r_inner++;
                 if (st == ST_INNER) {
                     if (COUNT) c_inner++;
-                    const uint32_t off = cur_first * 32u; // siblings: one aligned 64-byte fetch
-                    const float4 l0 = ld16(nodes, off), l1 = ld16(nodes, off + 16u);
-                    const float4 q0 = ld16(nodes, off + 32u), q1 = ld16(nodes, off + 48u);
+                    const float4* np = rec16(nodes, cur_first * 2u); // siblings: one aligned 64-byte fetch
+                    const float4 l0 = np[0], l1 = np[1], q0 = np[2], q1 = np[3];
                     const float left = hit_aabb_s(lo, lidir, l0, l1);
                     const float right = hit_aabb_s(lo, lidir, q0, q1);
                     const bool lmiss = (left < -0.5f || left > best_t);
@@ -453,7 +462,9 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                             if (sp < depth) {
                                 const uint32_t ff = __float_as_uint(go_left ? q1.z : l1.z), fc = __float_as_uint(go_left ? q1.w : l1.w);
                                 const uint32_t nd = go_left ? cur_first + 1u : cur_first;
-                                stack[sp * RT_WAVE] = (fc < 16u && ff < 0x08000000u) ? (ff | (fc << 27)) : (RT_STACK_RELOAD | nd);
+                                const uint32_t e = (fc < 16u && ff < 0x08000000u) ? (ff | (fc << 27)) : (RT_STACK_RELOAD | nd);
+                                if (DEEP && sp >= RT_LDS_LEVELS) spill[(sp - RT_LDS_LEVELS) * spill_stride] = e;
+                                else stack[sp * RT_WAVE] = e;
                                 sp++;
                             }
                             else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
@@ -466,8 +477,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
         } else if (n_leaf >= n_prim) {
             if (COUNT) r_leaf++;
             if (st == ST_LEAF) {
-                const uint32_t off = cur_first * 48u;
-                const float4 a0 = ld16(tris, off), a1 = ld16(tris, off + 16u), a2 = ld16(tris, off + 32u);
+                const float4* tp = rec16(tris, cur_first * 3u);
+                const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
                 if (COUNT) c_tri++;
                 float u, v;
                 const float t = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
@@ -509,9 +520,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
                 else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
                 p = cb + k;
-                const uint32_t poff = p * (uint32_t)sizeof(PrimX);
-                const float4 m0 = ld16(sc.primx, poff), m1 = ld16(sc.primx, poff + 16u), m2 = ld16(sc.primx, poff + 32u),
-                             m3 = ld16(sc.primx, poff + 48u);
+                const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
+                const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], m3 = pp[3];
                 const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
                 // transform_ray + scale factor, shader.wgsl:604-607
                 const f3 td = xform_dir(d, inv);
@@ -521,7 +531,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 lidir = rcp3(ld);
                 const uint32_t root = __float_as_uint(m3.x);
                 mode = __float_as_uint(m3.y) & 3u;
-                const float4 r0 = ld16(nodes, root * 32u), r1 = ld16(nodes, root * 32u + 16u);
+                const float4* rp = rec16(nodes, root * 2u);
+                const float4 r0 = rp[0], r1 = rp[1];
                 if (COUNT) c_prims++;
                 if (!(hit_aabb_s(lo, lidir, r0, r1) < -0.5f)) { // shader.wgsl:448
                     best_t = closest_t * scale;

@@ -72,7 +72,9 @@ struct rthip_ctx {
     std::vector<HostNode> host_nodes;
     std::vector<uint32_t> prim_roots;
     std::map<uint32_t, NanWalk> nan_walks; // by stack depth
-    float4*   partial = nullptr;    // frames_cap x n_pixels accumulation slots
+    float4*   partial = nullptr;
+    uint32_t* spill = nullptr;      // deep-stack columns (levels beyond the LDS part), allocated on first use
+    uint64_t  spill_words = 0;    // frames_cap x n_pixels accumulation slots
     uint32_t  frames_cap = 0;       // frames one launch group can hold
     uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors
     int32_t*  tap_tri = nullptr;
@@ -128,13 +130,14 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); c->d_tris = nullptr; c->d_primx = nullptr; free_dev(c->d_exts);
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
 
 void free_frame_buffers(rthip_ctx* c) {
-    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial);
+    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill);
+    c->spill_words = 0;
     c->frames_cap = 0;
     free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
     c->buf_pixels = 0;
@@ -340,10 +343,10 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (s->n_texels && !s->texels) return fail(c, RTHIP_ERR_INVALID, "upload_scene: null texel array");
     if (s->n_nodes >= 0x7FFFFFFFull || s->n_tris >= 0x7FFFFFFFull || s->n_prims >= 0x7FFFFFFFu)
         return fail(c, RTHIP_ERR_INVALID, "upload_scene: more than 2^31-1 nodes, triangles or primitives");
-    // the kernels address nodes, triangles and primitives with 32-bit byte offsets
-    if ((s->n_nodes + s->n_prims + 1) * 32ull >= 0xFFFFFFFFull || s->n_tris * 48ull >= 0xFFFFFFFFull || s->n_prims * 96ull >= 0xFFFFFFFFull)
-        return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: node or triangle array of 4 GiB or more (%llu nodes, %llu triangles)",
-                    (unsigned long long)s->n_nodes, (unsigned long long)s->n_tris);
+    // the kernels address records by a 32-bit count of 16-byte units: 64 GiB per array
+    if (s->n_tris * 3ull >= 0xFFFFFFFFull || s->n_prims * 6ull >= 0xFFFFFFFFull)
+        return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: triangle or primitive array of 64 GiB or more (%llu triangles, %u primitives)",
+                    (unsigned long long)s->n_tris, s->n_prims);
 
     const HostNode*   nodes = static_cast<const HostNode*>(s->nodes);
     const HostTri*    tris = static_cast<const HostTri*>(s->tris);
@@ -467,24 +470,9 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         if (bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    // nodes, triangles and primitive records share one arena (64-byte aligned parts, and 64 spare
-    // bytes so that a 64-byte fetch at the start of any record stays inside it)
-    auto align64 = [](uint64_t v) { return (v + 63ull) & ~63ull; };
-    const uint64_t tri_base = align64(sizeof(HostNode) * n_dev_nodes);
-    const uint64_t primx_base = align64(tri_base + sizeof(float) * dev_tris.size() + 16);
-    const uint64_t arena_bytes = align64(primx_base + sizeof(PrimX) * primx.size()) + 64;
-    if (arena_bytes >= 0xFFFFFFFFull)
-        return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: nodes + triangles of 4 GiB or more (%llu nodes, %llu triangles)",
-                    (unsigned long long)s->n_nodes, (unsigned long long)s->n_tris);
-    HIP_TRY(c, hipMalloc(&c->d_nodes, arena_bytes));
-    HIP_TRY(c, hipMemset(c->d_nodes, 0, arena_bytes));
-    HIP_TRY(c, hipMemcpy(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes, hipMemcpyHostToDevice));
-    if (!dev_tris.empty()) HIP_TRY(c, hipMemcpy(static_cast<char*>(c->d_nodes) + tri_base, dev_tris.data(), sizeof(float) * dev_tris.size(), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(static_cast<char*>(c->d_nodes) + primx_base, primx.data(), sizeof(PrimX) * primx.size(), hipMemcpyHostToDevice));
-    c->d_tris = static_cast<char*>(c->d_nodes) + tri_base;     // views into the arena, not owned
-    c->d_primx = static_cast<char*>(c->d_nodes) + primx_base;
-    c->sc.tri_base = (uint32_t)tri_base;
-    c->sc.primx_base = (uint32_t)primx_base;
+    HIP_TRY(c, upload(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes));
+    HIP_TRY(c, upload(c->d_tris, dev_tris.data(), sizeof(float) * dev_tris.size()));
+    HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
     HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
     HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
     HIP_TRY(c, upload(c->d_texels, s->texels, sizeof(uint32_t) * s->n_texels));
@@ -640,11 +628,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         q[k].s0 = base; q[k].s1 = base + cap; q[k].s2 = base + 2 * cap; q[k].s3 = base + 3 * cap;
     }
 
-    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, P.stack_depth > 24 ? 64u : 24u));
-    const bool deep = P.stack_depth > 24;
+    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
+    const bool deep = P.stack_depth > RT_LDS_LEVELS;
     int ext_blocks;
-    if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, 64>, 256) : occupancy_blocks(k_extend<true, 24>, 256);
-    else ext_blocks = deep ? occupancy_blocks(k_extend<false, 64>, 256) : occupancy_blocks(k_extend<false, 24>, 256);
+    if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, true>, 256) : occupancy_blocks(k_extend<true, false>, 256);
+    else ext_blocks = deep ? occupancy_blocks(k_extend<false, true>, 256) : occupancy_blocks(k_extend<false, false>, 256);
     if (const char* e = std::getenv("RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
         const int v = std::atoi(e);
         if (v > 0 && v <= 16) ext_blocks = v;
@@ -654,6 +642,16 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const uint32_t nf = std::min(group, n_frames - f0);
         const uint64_t slots = (uint64_t)ga.n_tiles * 64 * nf;
         const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (slots + 255) / 256);
+        if (deep) { // stack levels beyond the LDS part: one dword column per thread of the extend grid
+            const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_LDS_LEVELS) * ext_grid * 256;
+            if (c->spill_words < words) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                free_dev_t(c->spill);
+                c->spill_words = 0;
+                HIP_TRY(c, hipMalloc((void**)&c->spill, sizeof(uint32_t) * words));
+                c->spill_words = words;
+            }
+        }
         const uint32_t shade_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (slots + 255) / 256);
         const uint32_t gen_grid = (uint32_t)((slots + 255) / 256);
         const bool overwrite = (c->reject_hist == 1);
@@ -672,6 +670,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.sc = c->sc;
             ea.in = q[b & 1];
             ea.hits = c->hits;
+            ea.spill = c->spill;
             ea.count_in = c->ctrl + b;
             ea.cursor = c->ctrl + 64 + b;
             ea.stack_depth = P.stack_depth;
@@ -689,11 +688,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             {
                 StageTimer t(c, timing, RTHIP_STAGE_EXTEND);
                 if (count) {
-                    if (deep) hipLaunchKernelGGL((k_extend<true, 64>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
-                    else hipLaunchKernelGGL((k_extend<true, 24>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                    if (deep) hipLaunchKernelGGL((k_extend<true, true>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                    else hipLaunchKernelGGL((k_extend<true, false>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
                 } else {
-                    if (deep) hipLaunchKernelGGL((k_extend<false, 64>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
-                    else hipLaunchKernelGGL((k_extend<false, 24>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                    if (deep) hipLaunchKernelGGL((k_extend<false, true>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
+                    else hipLaunchKernelGGL((k_extend<false, false>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
                 }
             }
             ShadeArgs sa{};
