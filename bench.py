@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=1)
     ap.add_argument("--terrain-n", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opaque", action="store_true", help="diagnostic: treat MASK/BLEND materials as opaque")
     ap.add_argument("--first-frame", type=int, default=1, help="frame index of the first timed step (RNG key)")
     args = ap.parse_args()
 
@@ -112,6 +113,8 @@ def main():
     res = tuple(int(v) for v in args.res.lower().split("x"))
     scene, workload_name = build_workload(args)
     arrays = scene.arrays()
+    if args.opaque:
+        arrays["prims"]["material"]["alpha_settings"] = 0
     uniforms = scene.frame_uniforms(res, frame=1, reject_hist=1)
 
     ctx = device.Context(local_rank if distributed else 0)

@@ -9,20 +9,18 @@
 
 // ------------------------------------------------------------------ records in HBM
 
-// Extend-stage view of a primitive: 24 dwords.  The first 64 bytes are what a lane needs when it
-// enters the primitive (four 16-byte loads); wbox is a padded world-space bound of the root box,
-// read through the scalar cache by the wave-uniform culling scan.  inv holds rows 0..2 of the
-// four columns of the uploaded inv_transform (scene.rs:185).
+// Extend-stage view of a primitive.  The first 64 bytes are what a lane needs when it enters the
+// primitive (four 16-byte loads).  inv holds rows 0..2 of the four columns of the uploaded
+// inv_transform (scene.rs:185).
 struct PrimX {
     float    inv[12];
     uint32_t root;            // device node index of the BVH root
     uint32_t alpha_settings;  // scene.rs:164, 170-177
     uint32_t albedo_offset, albedo_size;
-    float    wbox[6];
     uint32_t albedo_texcoord;
-    uint32_t pad;
+    uint32_t pad[3];
 };
-static_assert(sizeof(PrimX) == 96, "PrimX");
+static_assert(sizeof(PrimX) == 80, "PrimX");
 
 // Uploaded records, read as-is by the shade stage.
 struct TexRefD { uint32_t offset, size; };
@@ -49,13 +47,18 @@ struct SceneDev {
     const float4*     tris;     // 3 float4 per triangle: (p0,0)(e1,0)(e2,0)
     const float4*     exts;     // 6 float4 per triangle: 3 x {uv0, uv1 | oct normal, colour, pad}
     const PrimX*      primx;
+    // padded world-space bounds of the primitives' root boxes for the culling scan, in groups of
+    // eight primitives: [group][min x, min y, min z, max x, max y, max z][8] (192 bytes a group,
+    // read through the scalar cache); the slots past the last primitive are padding whose
+    // result the scan discards
+    const float*      wbounds;
     const PrimitiveD* prims;
     const uint32_t*   texels;
     const float4*     env;
     uint64_t          n_texels;
     uint32_t          env_w, env_h;
     uint32_t          n_prims;
-    uint32_t          pad;
+    uint32_t          n_prim_groups;  // ceil(n_prims / 8)
 };
 
 // Path state: four float4 streams per queue slot, so every access is a 16-byte-per-lane,

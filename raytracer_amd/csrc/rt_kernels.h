@@ -199,7 +199,8 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 
 // Loads through the scalar cache: the address is wave-uniform and the data is never written by
 // a kernel, which the constant address space tells the compiler.
-typedef const __attribute__((address_space(4))) float* rt_cfloat_p;
+typedef float rt_float8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) rt_float8* rt_cfloat8_p;
 
 // Address of a record given its position in 16-byte units (one 64-bit shift-add; the record's
 // further 16-byte pieces are immediate offsets of the loads).  32 bits of units span 64 GiB.
@@ -245,7 +246,7 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // slowest ray of a batch is done.
 //
 // Candidate primitives come from a wave-uniform scan of padded world-space bounds (scalar
-// loads), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
+// loads of eight primitives' bounds at a time), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
 // bound the ray misses changes nothing the reference would compute.
 //
 // The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free) for
@@ -414,18 +415,28 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
             const f3 r = rcp3(d);
             const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
             const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+            // bounds come eight primitives at a time: six 32-byte scalar loads per group
             uint32_t m[4];
+            const uint32_t g0 = c0 >> 3;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 uint32_t mw = 0;
-                const uint32_t p0 = c0 + 32u * w;
-                const uint32_t pe = min(p0 + 32u, sc.n_prims);
-                for (uint32_t q = p0; q < pe; q++) {
-                    const rt_cfloat_p wb = (rt_cfloat_p)(sc.primx[q].wbox);
-                    const float b[6] = {wb[0], wb[1], wb[2], wb[3], wb[4], wb[5]};
-                    mw |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (q - p0);
+#pragma unroll 1
+                for (uint32_t gg = 0; gg < 4u; gg++) {
+                    const uint32_t g = g0 + 4u * w + gg;
+                    if (g >= sc.n_prim_groups) break;
+                    const rt_cfloat8_p bp = (rt_cfloat8_p)(sc.wbounds + (size_t)g * 48u);
+                    const rt_float8 lx = bp[0], ly = bp[1], lz = bp[2], hx = bp[3], hy = bp[4], hz = bp[5];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float b[6] = {lx[k], ly[k], lz[k], hx[k], hy[k], hz[k]};
+                        mw |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (gg * 8u + k);
+                    }
                 }
-                m[w] = mw;
+                // the last group is padded to eight: drop the bits of primitives that do not exist
+                const uint32_t first = c0 + 32u * w;
+                const uint32_t have = sc.n_prims > first ? min(sc.n_prims - first, 32u) : 0u;
+                m[w] = have >= 32u ? mw : (mw & ((1u << have) - 1u));
             }
             if (mine) {
                 mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];

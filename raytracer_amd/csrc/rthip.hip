@@ -48,6 +48,7 @@ struct rthip_ctx {
     void*     d_tris = nullptr;
     void*     d_exts = nullptr;
     void*     d_primx = nullptr;
+    void*     d_wbounds = nullptr;
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
     void*     d_env = nullptr;
@@ -130,7 +131,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx);
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -333,6 +334,37 @@ int rthip_set_stream(rthip_ctx* c, void* hip_stream) {
     return RTHIP_OK;
 }
 
+// Walks the device tree the way a NaN-direction ray does, with a stack of `depth` entries whose
+// overflowing pushes are dropped (shader.wgsl:306-313), and counts the steps.
+static const NanWalk& nan_walk(rthip_ctx* c, uint32_t depth) {
+    auto it = c->nan_walks.find(depth);
+    if (it != c->nan_walks.end()) return it->second;
+    NanWalk w;
+    std::vector<uint32_t> stack(depth ? depth : 1);
+    for (uint32_t root : c->prim_roots) {
+        uint32_t sp = 0;
+        uint32_t first = c->host_nodes[root].first, count = c->host_nodes[root].count;
+        for (;;) {
+            if (count > 0) { // leaf: every triangle is tested, none is hit
+                w.leaf++;
+                w.tri += count;
+                if (sp == 0) break;
+                const HostNode& n = c->host_nodes[stack[--sp]];
+                first = n.first;
+                count = n.count;
+            } else {         // inner: both children "hit"; left < right is false, so right first
+                w.inner++;
+                if (sp < depth) stack[sp++] = first;
+                else w.dropped++;
+                const HostNode& n = c->host_nodes[first + 1];
+                first = n.first;
+                count = n.count;
+            }
+        }
+    }
+    return c->nan_walks.emplace(depth, w).first->second;
+}
+
 int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!s) return fail(c, RTHIP_ERR_INVALID, "upload_scene: null scene");
@@ -344,7 +376,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (s->n_nodes >= 0x7FFFFFFFull || s->n_tris >= 0x7FFFFFFFull || s->n_prims >= 0x7FFFFFFFu)
         return fail(c, RTHIP_ERR_INVALID, "upload_scene: more than 2^31-1 nodes, triangles or primitives");
     // the kernels address records by a 32-bit count of 16-byte units: 64 GiB per array
-    if (s->n_tris * 3ull >= 0xFFFFFFFFull || s->n_prims * 6ull >= 0xFFFFFFFFull)
+    if (s->n_tris * 3ull >= 0xFFFFFFFFull || s->n_prims * 5ull >= 0xFFFFFFFFull)
         return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: triangle or primitive array of 64 GiB or more (%llu triangles, %u primitives)",
                     (unsigned long long)s->n_tris, s->n_prims);
 
@@ -412,6 +444,8 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     }
 
     std::vector<PrimX> primx(s->n_prims);
+    const uint32_t n_prim_groups = (s->n_prims + 7u) / 8u;
+    std::vector<float> wbounds((size_t)n_prim_groups * 48, 0.0f); // padding slots stay zero; the scan masks them off
     for (uint32_t p = 0; p < s->n_prims; p++) {
         const PrimitiveD& pr = prims[p];
         PrimX& x = primx[p];
@@ -458,7 +492,8 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
                 }
             }
         }
-        std::memcpy(x.wbox, wb, sizeof wb);
+        float* grp = &wbounds[(size_t)(p >> 3) * 48];
+        for (int k = 0; k < 6; k++) grp[k * 8 + (p & 7u)] = wb[k];
     }
 
     DeviceGuard g(c->device);
@@ -473,6 +508,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     HIP_TRY(c, upload(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes));
     HIP_TRY(c, upload(c->d_tris, dev_tris.data(), sizeof(float) * dev_tris.size()));
     HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
+    HIP_TRY(c, upload(c->d_wbounds, wbounds.data(), sizeof(float) * wbounds.size()));
     HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
     HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
     HIP_TRY(c, upload(c->d_texels, s->texels, sizeof(uint32_t) * s->n_texels));
@@ -482,6 +518,8 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->sc.tris = static_cast<const float4*>(c->d_tris);
     c->sc.exts = static_cast<const float4*>(c->d_exts);
     c->sc.primx = static_cast<const PrimX*>(c->d_primx);
+    c->sc.wbounds = static_cast<const float*>(c->d_wbounds);
+    c->sc.n_prim_groups = n_prim_groups;
     c->sc.prims = static_cast<const PrimitiveD*>(c->d_prims);
     c->sc.texels = static_cast<const uint32_t*>(c->d_texels);
     c->sc.env = static_cast<const float4*>(c->d_env);
@@ -496,6 +534,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     for (uint32_t p = 0; p < s->n_prims; p++) c->prim_roots[p] = primx[p].root;
     c->host_nodes.swap(dev_nodes);
     c->nan_walks.clear();
+    (void)nan_walk(c, 23); // the default stack depth; other depths are walked at their first render
     c->node_index_map.swap(map);
     c->have_scene = true;
     c->reject_hist = 1;
@@ -531,37 +570,6 @@ void rthip_default_params(rthip_render_params* p) {
     p->stack_depth = 23;
     p->enable_sun = 0;
     p->flags = 0;
-}
-
-// Walks the device tree the way a NaN-direction ray does, with a stack of `depth` entries whose
-// overflowing pushes are dropped (shader.wgsl:306-313), and counts the steps.
-static const NanWalk& nan_walk(rthip_ctx* c, uint32_t depth) {
-    auto it = c->nan_walks.find(depth);
-    if (it != c->nan_walks.end()) return it->second;
-    NanWalk w;
-    std::vector<uint32_t> stack(depth ? depth : 1);
-    for (uint32_t root : c->prim_roots) {
-        uint32_t sp = 0;
-        uint32_t first = c->host_nodes[root].first, count = c->host_nodes[root].count;
-        for (;;) {
-            if (count > 0) { // leaf: every triangle is tested, none is hit
-                w.leaf++;
-                w.tri += count;
-                if (sp == 0) break;
-                const HostNode& n = c->host_nodes[stack[--sp]];
-                first = n.first;
-                count = n.count;
-            } else {         // inner: both children "hit"; left < right is false, so right first
-                w.inner++;
-                if (sp < depth) stack[sp++] = first;
-                else w.dropped++;
-                const HostNode& n = c->host_nodes[first + 1];
-                first = n.first;
-                count = n.count;
-            }
-        }
-    }
-    return c->nan_walks.emplace(depth, w).first->second;
 }
 
 int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride, const rthip_render_params* params) {

@@ -253,7 +253,8 @@ class Scene:
         if not ptr or count == 0:
             return np.zeros(0, dtype=dtype)
         n = count * np.dtype(dtype).itemsize
-        return np.frombuffer(C.string_at(ptr, n), dtype=dtype).copy()
+        # one copy, and no 2 GiB limit (C.string_at goes through a Python bytes object)
+        return np.frombuffer((C.c_char * n).from_address(ptr), dtype=dtype).copy()
 
     @property
     def n_cameras(self):
