@@ -26,13 +26,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor figure
 
 
 def extend_algorithmic_bytes(c):
-    """Bytes the extend stage must move for the work counted in `c`, at the device record sizes:
-    per ray 32 B of path state in and 16 B of hit record out; per primitive visited 96 B (ray
-    transform, root index, alpha settings, world bound) and 32 B of root node; per inner step
-    64 B (one sibling pair); per popped node 8 B is not counted; per triangle test 36 B (nine
-    floats of a 48-byte record); per alpha test 24 B of UVs and 4 B of texel."""
-    return (48 * c["rays"] + (96 + 32) * c["prims_visited"] + 64 * c["inner_steps"] +
-            36 * c["tri_tests"] + 28 * c["alpha_tests"])
+    """Bytes the extend stage must move for the work counted in `c`: 32 B per node record touched
+    (a root per primitive entered, two children per inner step), 36 B per triangle test (nine
+    floats) and 80 B per primitive entered (64 B of inverse transform + 16 B of root index, alpha
+    settings and albedo reference)."""
+    return (32 * (c["prims_visited"] + 2 * c["inner_steps"]) + 36 * c["tri_tests"] + 80 * c["prims_visited"])
 
 
 def build_workload(args):
@@ -52,8 +50,8 @@ def build_workload(args):
 
 def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
     """Times the CPU oracle (the build's own restatement, not the reference binary) on the first
-    frames of the same workload, all host threads the box grants this process.  A strided sample
-    of frame 1 sizes the run to about target_seconds of CPU work."""
+    frames of the same workload, all host threads the box grants this process.  One untimed frame
+    sizes the run to about target_seconds of CPU work."""
     from oracle import orc
     env = arrays["env"]
     sc = orc.make_scene(arrays["tris"], arrays["tri_exts"], arrays["nodes"], arrays["prims"],
@@ -61,12 +59,9 @@ def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
     op = orc.Params(params.max_bounces, params.term_prob, params.aperture_radius, params.stack_depth, 0)
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     h = int(np.ascontiguousarray(uniforms).view(np.uint8).reshape(-1)[580:584].view(np.uint32)[0])
-    step = max(1, h // 16)
     t0 = time.perf_counter()
-    r = orc.render(sc, uniforms, op, 1, 1, 1, n_threads=cores, row_start=step // 2, row_step=step)
-    dt = time.perf_counter() - t0
-    rows = len(range(step // 2, h, step))
-    frame_seconds = dt * h / rows
+    orc.render(sc, uniforms, op, 1, 1, 1, n_threads=cores)   # one frame sizes the timed run
+    frame_seconds = time.perf_counter() - t0
     frames = int(min(64, max(1, round(target_seconds / max(frame_seconds, 1e-3)))))
     t0 = time.perf_counter()
     r = orc.render(sc, uniforms, op, 1, frames, 1, n_threads=cores)
@@ -79,7 +74,7 @@ def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="atrium")
     ap.add_argument("--res", default="1920x1080")
@@ -175,6 +170,7 @@ def main():
         dist.all_reduce(rt, op=dist.ReduceOp.SUM)
         rays_total = int(rt.item())
 
+    copy_gbs = ctx.copy_bandwidth() if rank == 0 else 0.0
     if rank == 0:
         ext = timing["extend"]
         ext_bytes = extend_algorithmic_bytes(counters)
@@ -214,6 +210,7 @@ def main():
                 "kernel": "k_extend",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
+                "peak_stream_copy": round(copy_gbs, 1),
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None,

@@ -174,6 +174,11 @@ int rthip_reset_counters(rthip_ctx* ctx);
 int rthip_get_timing(rthip_ctx* ctx, rthip_timing* out);
 int rthip_reset_timing(rthip_ctx* ctx);
 
+/* Measurement aid: times `repeats` device-to-device copies of `bytes` bytes on the context's
+ * stream and returns the achieved HBM traffic in GB/s (bytes read + bytes written per second), the
+ * stream-copy ceiling that bandwidth fractions can be quoted against.  No counterpart upstream. */
+int rthip_copy_bandwidth(rthip_ctx* ctx, uint64_t bytes, uint32_t repeats, double* gb_per_s);
+
 int rthip_synchronize(rthip_ctx* ctx);
 
 #ifdef __cplusplus

@@ -904,6 +904,33 @@ int rthip_reset_timing(rthip_ctx* c) {
     return RTHIP_OK;
 }
 
+int rthip_copy_bandwidth(rthip_ctx* c, uint64_t bytes, uint32_t repeats, double* gb_per_s) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!gb_per_s || bytes == 0 || repeats == 0) return fail(c, RTHIP_ERR_INVALID, "copy_bandwidth: null result, zero bytes or zero repeats");
+    DeviceGuard g(c->device);
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream); // untimed first touch
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (uint32_t r = 0; r < repeats && e == hipSuccess; r++) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "copy_bandwidth: %s", hipGetErrorString(e));
+    *gb_per_s = ms > 0.0f ? 2.0 * (double)bytes * repeats / ((double)ms * 1e-3) / 1e9 : 0.0;
+    return RTHIP_OK;
+}
+
 int rthip_synchronize(rthip_ctx* c) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     DeviceGuard g(c->device);

@@ -24,7 +24,7 @@ EXPORTS = (
     "rthip_read_taps", "rthip_read_nodes_device_layout", "rthip_read_node_index_map",
     "rthip_read_tri_order", "rthip_read_tris_device_layout", "rthip_resolve",
     "rthip_get_counters", "rthip_reset_counters", "rthip_get_timing", "rthip_reset_timing",
-    "rthip_synchronize",
+    "rthip_synchronize", "rthip_copy_bandwidth",
 )
 
 
@@ -87,6 +87,7 @@ def lib():
         l.rthip_set_frame_uniforms.argtypes = [vp, vp]
         l.rthip_default_params.argtypes = [C.POINTER(RenderParams)]
         l.rthip_reserve.argtypes = [vp, C.c_uint32]
+        l.rthip_copy_bandwidth.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
         l.rthip_default_params.restype = None
         l.rthip_render.argtypes = [vp, u32, u32, u32, C.POINTER(RenderParams)]
         l.rthip_bind_accum.argtypes = [vp, vp, u64]
@@ -190,6 +191,12 @@ class Context:
     def reserve(self, n_frames):
         """Allocate the work buffers for calls of up to n_frames frames ahead of the first render."""
         self._check(lib().rthip_reserve(self._h, int(n_frames)))
+
+    def copy_bandwidth(self, nbytes=1 << 30, repeats=8):
+        """Device-to-device stream-copy ceiling in GB/s (read + write traffic)."""
+        out = C.c_double()
+        self._check(lib().rthip_copy_bandwidth(self._h, int(nbytes), int(repeats), C.byref(out)))
+        return float(out.value)
 
     def synchronize(self):
         self._check(lib().rthip_synchronize(self._h))
