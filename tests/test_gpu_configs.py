@@ -1,0 +1,186 @@
+"""GPU parity at the sizes the benchmark configurations name.
+
+Small cases are compared pixel by pixel in test_gpu_parity.py.  Here the configurations run at
+their full resolution: against the oracle where the oracle finishes in seconds (all of the 512x512
+cases, sampled rows of the 1080p case), and through properties that do not depend on the size
+(bit-identical results for any grouping of the frames, for repeated runs and for striped
+accumulation; the sample count in the alpha lane).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import device, procedural
+from util import oracle_params, oracle_scene, psnr, tonemapped
+
+pytestmark = pytest.mark.gpu
+
+THREADS = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = device.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def atrium():
+    s = procedural.atrium_scene()
+    return s, s.arrays()
+
+
+def render(ctx, scene, arrays, res, first, n, stride=1, params=None, upload=True):
+    if upload:
+        ctx.upload_scene(arrays)
+    ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=first, reject_hist=1))
+    ctx.render(first, n, stride, params or device.default_params())
+    return ctx.read_accum()
+
+
+def test_config1_box_512_one_sample(ctx):
+    """Box, 512x512, 1 spp, reference parameters (8 bounces, 50 % termination, DoF)."""
+    s = procedural.box_scene()
+    a = s.arrays()
+    res = (512, 512)
+    p = device.default_params()
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 1, 1, p)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    ref = orc.render(oracle_scene(a), u, oracle_params(p), 1, 1, 1, taps=True, n_threads=THREADS)
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.9999
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.999
+    same = got["seed"] == ref["seed"]
+    np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
+    assert got["counters"]["paths"] == 512 * 512
+    assert abs(got["counters"]["rays"] - ref["counters"]["rays"]) <= 2e-3 * ref["counters"]["rays"]
+
+
+def test_config2_blob_512_64_samples(ctx):
+    """Suzanne-sized single primitive (15 744 triangles, metallic 1 / roughness 1), 512x512, 64 spp."""
+    s = procedural.blob_scene()
+    a = s.arrays()
+    res = (512, 512)
+    p = device.default_params()
+    got = render(ctx, s, a, res, 1, 64, params=p)
+    ref = orc.render(oracle_scene(a), s.frame_uniforms(res, frame=1, reject_hist=1), oracle_params(p), 1, 64, 1,
+                     n_threads=THREADS)["accum"]
+    assert np.all(got[..., 3] == 64.0)
+    assert psnr(tonemapped(got), tonemapped(ref)) >= 45.0
+
+
+def test_config3_atrium_1080p_rows_match_oracle(ctx, atrium):
+    """Headline workload at full size: every 135th row of frames 1 and 2 against the oracle."""
+    s, a = atrium
+    res = (1920, 1080)
+    p = device.default_params(max_bounces=4)
+    p.flags |= device.FLAG_TAPS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.render(1, 2, 1, p)
+    got = dict(accum=ctx.read_accum(), **ctx.read_taps())
+    ref = orc.render(oracle_scene(a), u, oracle_params(p), 1, 2, 1, taps=True, n_threads=THREADS,
+                     row_start=67, row_step=135)
+    rows = np.arange(67, 1080, 135)
+    assert float((got["tri"][rows] == ref["tri"][rows]).mean()) >= 0.9999
+    assert float((got["seed"][rows] == ref["seed"][rows]).mean()) >= 0.998
+    same = got["seed"][rows] == ref["seed"][rows]
+    np.testing.assert_allclose(got["accum"][rows][same], ref["accum"][rows][same], rtol=2e-3, atol=2e-4)
+    assert np.all(got["accum"][..., 3] == 2.0)
+
+
+def test_config3_frame_grouping_is_invisible(ctx, atrium):
+    """40 frames in one call (groups of 32 + 8), in groups of 7, and one frame per call give the
+    same accumulator bit for bit; so does a second run."""
+    s, a = atrium
+    res = (1920, 1080)
+    p = device.default_params(max_bounces=4)
+    n = 40
+    whole = render(ctx, s, a, res, 1, n, params=p)
+    again = render(ctx, s, a, res, 1, n, params=p, upload=False)
+    assert np.array_equal(whole, again)
+    old = os.environ.get("RTHIP_FRAMES_IN_FLIGHT")
+    try:
+        os.environ["RTHIP_FRAMES_IN_FLIGHT"] = "7"
+        sevens = render(ctx, s, a, res, 1, n, params=p, upload=False)
+    finally:
+        if old is None:
+            del os.environ["RTHIP_FRAMES_IN_FLIGHT"]
+        else:
+            os.environ["RTHIP_FRAMES_IN_FLIGHT"] = old
+    assert np.array_equal(whole, sevens)
+    ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+    for f in range(1, n + 1):
+        ctx.render(f, 1, 1, p)
+    assert np.array_equal(whole, ctx.read_accum())
+    assert np.all(whole[..., 3] == float(n))
+    assert np.isfinite(whole).all()
+
+
+def test_config4_4k_striped_accumulation(ctx, atrium):
+    """3840x2160: the frames of two ranks (stride 2) accumulated on top of each other hold the same
+    samples as one run over all frames; only the order of the float additions differs."""
+    s, a = atrium
+    res = (3840, 2160)
+    p = device.default_params(max_bounces=4)
+    n = 8
+    full = render(ctx, s, a, res, 1, n, params=p)
+    ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+    ctx.render(1, n // 2, 2, p)     # rank 0 of 2: frames 1, 3, 5, 7
+    ctx.render(2, n // 2, 2, p)     # rank 1 of 2: frames 2, 4, 6, 8
+    striped = ctx.read_accum()
+    assert np.all(full[..., 3] == float(n)) and np.array_equal(striped[..., 3], full[..., 3])
+    np.testing.assert_allclose(striped, full, rtol=1e-5, atol=1e-5)
+    img = ctx.resolve()
+    assert img.shape == (2160, 3840, 4) and np.all(img[..., 3] == 255)
+
+
+def test_config5_tiled_terrain_deep_stack(ctx):
+    """Tiled terrain merged into one BVH (here 12x12 tiles, 1.2 M triangles), stack depth 48: the
+    part of the stack beyond the LDS levels lives in global memory."""
+    s = procedural.terrain_scene(tiles=12, env_size=(128, 64))
+    a = s.arrays()
+    res = (256, 144)
+    p = device.default_params(max_bounces=4, stack_depth=48)
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 2, 1, p)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    ref = orc.render(oracle_scene(a), u, oracle_params(p), 1, 2, 1, taps=True, n_threads=THREADS)
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.9999
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.999
+    same = got["seed"] == ref["seed"]
+    np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
+    assert got["counters"]["stack_overflows"] == ref["counters"]["stack_overflows"] == 0
+
+
+def test_shallow_stack_on_deep_tree_overflows_like_the_oracle(ctx):
+    """The same tree with the reference's 23 entries and with 26 (two levels in global memory)."""
+    s = procedural.terrain_scene(tiles=6, env_size=(128, 64))
+    a = s.arrays()
+    res = (128, 72)
+    for depth in (4, 26):
+        p = device.default_params(max_bounces=2, stack_depth=depth)
+        p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+        u = s.frame_uniforms(res, frame=3, reject_hist=1)
+        ctx.upload_scene(a)
+        ctx.set_frame_uniforms(u)
+        ctx.reset_counters()
+        ctx.render(3, 1, 1, p)
+        got = dict(counters=ctx.counters(), **ctx.read_taps())
+        ref = orc.render(oracle_scene(a), u, oracle_params(p), 3, 1, 1, taps=True, n_threads=THREADS)
+        assert float((got["tri"] == ref["tri"]).mean()) >= 0.999
+        for k in ("inner_steps", "tri_tests", "stack_overflows"):
+            assert abs(got["counters"][k] - ref["counters"][k]) <= max(8, 2e-3 * ref["counters"][k]), (depth, k)
+        assert (ref["counters"]["stack_overflows"] > 0) == (depth == 4)
