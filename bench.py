@@ -96,7 +96,9 @@ def main():
     n_gpus = args.gpus
     if world != n_gpus and world > 1:
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
+    # under torch.distributed.run the collective path is used even for one rank, so that it can
+    # be exercised on a one-GPU box
+    distributed = world > 1 or "RANK" in os.environ
 
     torch = dist = None
     if distributed:
