@@ -9,18 +9,24 @@
 
 // ------------------------------------------------------------------ records in HBM
 
-// Extend-stage view of a primitive.  The first 64 bytes are what a lane needs when it enters the
-// primitive (four 16-byte loads).  inv holds rows 0..2 of the four columns of the uploaded
-// inv_transform (scene.rs:185).
+// Extend-stage view of a primitive.  The first 96 bytes are what a lane needs when it enters the
+// primitive (six independent 16-byte loads): inv holds rows 0..2 of the four columns of the
+// uploaded inv_transform (scene.rs:185), root_node is a copy of the BVH root's record so that the
+// root test does not wait for a second, dependent fetch.
 struct PrimX {
     float    inv[12];
     uint32_t root;            // device node index of the BVH root
-    uint32_t alpha_settings;  // scene.rs:164, 170-177
+    uint32_t alpha_settings;  // scene.rs:164, 170-177, plus RT_PRIMX_NESTED_ROOT in an unused bit
     uint32_t albedo_offset, albedo_size;
+    float    root_box[6];     // the root node: min.xyz, max.xyz,
+    uint32_t root_first, root_count; // first, count (first already in device numbering)
     uint32_t albedo_texcoord;
     uint32_t pad[3];
 };
-static_assert(sizeof(PrimX) == 80, "PrimX");
+static_assert(sizeof(PrimX) == 112, "PrimX");
+// alpha_settings bit: the root is an inner node and both child boxes lie inside the root box (true
+// for every tree the reference's builder makes; checked at upload because any tree is accepted)
+#define RT_PRIMX_NESTED_ROOT 4u
 
 // Uploaded records, read as-is by the shade stage.
 struct TexRefD { uint32_t offset, size; };

@@ -376,7 +376,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (s->n_nodes >= 0x7FFFFFFFull || s->n_tris >= 0x7FFFFFFFull || s->n_prims >= 0x7FFFFFFFu)
         return fail(c, RTHIP_ERR_INVALID, "upload_scene: more than 2^31-1 nodes, triangles or primitives");
     // the kernels address records by a 32-bit count of 16-byte units: 64 GiB per array
-    if (s->n_tris * 3ull >= 0xFFFFFFFFull || s->n_prims * 5ull >= 0xFFFFFFFFull)
+    if (s->n_tris * 3ull >= 0xFFFFFFFFull || s->n_prims * 7ull >= 0xFFFFFFFFull)
         return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: triangle or primitive array of 64 GiB or more (%llu triangles, %u primitives)",
                     (unsigned long long)s->n_tris, s->n_prims);
 
@@ -453,7 +453,24 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         for (int col = 0; col < 4; col++)
             for (int row = 0; row < 3; row++) x.inv[col * 3 + row] = pr.inv_transform[col * 4 + row];
         x.root = map[pr.bvh_idx];
-        x.alpha_settings = pr.material.alpha_settings;
+        {
+            const HostNode& rn = dev_nodes[x.root];
+            std::memcpy(x.root_box, rn.aabb, sizeof x.root_box);
+            x.root_first = rn.first;
+            x.root_count = rn.count;
+        }
+        x.alpha_settings = pr.material.alpha_settings & ~RT_PRIMX_NESTED_ROOT;
+        {
+            const HostNode& rn = dev_nodes[map[pr.bvh_idx]];
+            if (rn.count == 0) {
+                bool inside = true;
+                for (int ch = 0; ch < 2; ch++) {
+                    const HostNode& cn = dev_nodes[rn.first + ch];
+                    for (int k = 0; k < 3; k++) inside = inside && cn.aabb[k] >= rn.aabb[k] && cn.aabb[3 + k] <= rn.aabb[3 + k];
+                }
+                if (inside) x.alpha_settings |= RT_PRIMX_NESTED_ROOT;
+            }
+        }
         x.albedo_offset = pr.material.albedo.offset;
         x.albedo_size = pr.material.albedo.size;
         x.albedo_texcoord = pr.material.albedo_texcoord;
