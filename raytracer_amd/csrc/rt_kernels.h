@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
         f3 dir = normalize(pixel_pos - origin0);
         const float theta = rnd(seed) * 2.0f * RT_PI; // rand_disk, shader.wgsl:669-673
         const float radius = sqrtf(rnd(seed));
-        const float ax = a.aperture_radius * (radius * cosf(theta));
-        const float ay = a.aperture_radius * (radius * sinf(theta));
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        const float ax = a.aperture_radius * (radius * cs);
+        const float ay = a.aperture_radius * (radius * sn);
         f3 origin = origin0 + right * ax;
         origin = origin + up * ay;
         pixel_pos = pixel_pos + dir * (a.focus - 1.0f);
@@ -613,19 +615,27 @@ __device__ __forceinline__ f3 rand_sphere(uint32_t& seed) {
     const float theta = rnd(seed) * 2.0f * RT_PI;
     const float z = rnd(seed) * 2.0f - 1.0f;
     const float radius = sqrtf(1.0f - z * z);
-    return F3(radius * cosf(theta), radius * sinf(theta), z);
+    float sn, cs;
+    sincosf(theta, &sn, &cs); // one argument reduction for both
+    return F3(radius * cs, radius * sn, z);
 }
 
 __device__ __forceinline__ f3 unpack_rgb(uint32_t x) { // shader.wgsl:175-182
     return F3((float)((x >> 24) & 255u) / 255.0f, (float)((x >> 16) & 255u) / 255.0f, (float)((x >> 8) & 255u) / 255.0f);
 }
-__device__ __forceinline__ f3 to_linear(f3 c) { // shader.wgsl:725-728
-    return F3(powf(c.x, 2.2f), powf(c.y, 2.2f), powf(c.z, 2.2f));
+// to_linear(unpack_rgba8(x).rgb), shader.wgsl:725-728 after 175-182: a channel is one of 256
+// values, so pow(k / 255, 2.2) comes from a table that every block fills with that very
+// expression at its start.
+__device__ __forceinline__ f3 linear_rgb(const float* lut, uint32_t x) {
+    return F3(lut[(x >> 24) & 255u], lut[(x >> 16) & 255u], lut[(x >> 8) & 255u]);
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     __shared__ uint32_t scratch[8];
+    __shared__ float lin_lut[256];
+    lin_lut[threadIdx.x & 255u] = powf((float)(threadIdx.x & 255u) / 255.0f, 2.2f);
+    __syncthreads();
     const uint32_t n = *a.count_in;
     const uint32_t n_pad = (n + 255u) & ~255u; // whole blocks stay in the loop together
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
                 if (m.albedo.size != 0u) {
                     const bool s1set = m.albedo_texcoord >= 1u;
                     if (COUNT) c_texel++;
-                    albedo = albedo * to_linear(unpack_rgb(fetch_texel(a.sc, m.albedo.offset, m.albedo.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y)));
+                    albedo = albedo * linear_rgb(lin_lut, fetch_texel(a.sc, m.albedo.offset, m.albedo.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
                 } else {
                     albedo = albedo * F3(0.01f, 0.02f, 0.03f);
                 }
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
                 if (m.emissive.size != 0u) {
                     const bool s1set = m.emissive_texcoord >= 1u;
                     if (COUNT) c_texel++;
-                    emissive = emissive * to_linear(unpack_rgb(fetch_texel(a.sc, m.emissive.offset, m.emissive.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y)));
+                    emissive = emissive * linear_rgb(lin_lut, fetch_texel(a.sc, m.emissive.offset, m.emissive.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
                 }
                 float metallic_chance = m.metallic_factor;
                 float roughness = m.roughness_factor;
