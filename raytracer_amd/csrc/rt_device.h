@@ -142,20 +142,8 @@ __device__ __forceinline__ float rnd(uint32_t& seed) {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (RT_WAVE - 1); }
 
-// Order-preserving compaction of the lanes with pred set: returns the slot of this lane in the
-// output queue (valid only where pred).  One atomic per wave.  Must be called with all 64
-// lanes of the wave active.
-__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
-    const unsigned long long m = __ballot(pred);
-    const uint32_t n = (uint32_t)__popcll(m);
-    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    uint32_t base = 0;
-    if (lane_id() == 0 && n) base = atomicAdd(counter, n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    return base + prefix;
-}
-
-// Same across a 256-thread block (4 waves): one atomic per block.  `scratch` is 8 dwords of LDS
+// Order-preserving compaction of the threads of a 256-thread block (4 waves) with pred set:
+// returns this thread's slot in the output queue (valid only where pred).  One atomic per block.  `scratch` is 8 dwords of LDS
 // owned by the caller.  Must be reached by every thread of the block.
 __device__ __forceinline__ uint32_t block_append(bool pred, uint32_t* counter, uint32_t* scratch) {
     const unsigned long long m = __ballot(pred);

@@ -1,10 +1,11 @@
-// The four stages of the path-tracing hot path as HIP kernels for gfx950 (wave64):
-//   generate  camera rays            (shader.wgsl:895-897, 741-779)
-//   extend    closest-hit traversal  (shader.wgsl:598-627, 442-525, 339-438)
-//   shade     miss / kill / BRDF     (shader.wgsl:898-914, 803-885, 941-951)
-//   resolve   mean + tonemap + sRGB  (shader.wgsl:969-1012; main.rs:116)
-// One launch of extend + shade per bounce; paths that survive a bounce are compacted into the
-// next queue with a ballot + prefix count and one atomic per wave.
+// The stages of the path-tracing hot path as HIP kernels for gfx950 (wave64):
+//   generate    camera rays of a group of frames  (shader.wgsl:895-897, 741-779)
+//   extend      closest-hit traversal             (shader.wgsl:598-627, 442-525, 339-438)
+//   shade       miss / kill / BRDF                (shader.wgsl:898-914, 803-885, 941-946)
+//   accumulate  frame-ordered sum into screen     (shader.wgsl:947-951)
+//   resolve     mean + tonemap + sRGB             (shader.wgsl:969-1012; main.rs:116)
+// One launch of extend + shade per bounce for all frames of the group; paths that survive a bounce are compacted into the
+// next queue with a ballot + prefix count and one atomic per 256-thread block.
 #pragma once
 
 #include "rt_device.h"
@@ -12,19 +13,6 @@
 #define RT_PI 3.141592654f  // shader.wgsl:11
 
 // ------------------------------------------------------------------ intersection primitives
-
-// intersect_aabb, shader.wgsl:415-438.  q0 = (min.xyz, max.x), q1 = (max.y, max.z, .., ..)
-__device__ __forceinline__ float hit_aabb(f3 o, f3 idir, float4 q0, float4 q1) {
-    const f3 bmin = F3(q0.x, q0.y, q0.z), bmax = F3(q0.w, q1.x, q1.y);
-    if (o.x >= bmin.x && o.y >= bmin.y && o.z >= bmin.z && o.x < bmax.x && o.y < bmax.y && o.z < bmax.z)
-        return 0.0f;
-    const f3 rmin = (bmin - o) * idir;
-    const f3 rmax = (bmax - o) * idir;
-    const float t0 = fmaxf(fminf(rmin.x, rmax.x), fmaxf(fminf(rmin.y, rmax.y), fminf(rmin.z, rmax.z)));
-    const float t1 = fminf(fmaxf(rmin.x, rmax.x), fminf(fmaxf(rmin.y, rmax.y), fmaxf(rmin.z, rmax.z)));
-    if (t0 > t1 || t0 < 0.0f) return -1.0f;
-    return t0;
-}
 
 // intersect, shader.wgsl:339-364, on a (p0, e1, e2) record.  Returns t or -1; u, v are the
 // barycentrics intersect_full (shader.wgsl:376-412) would recompute from the same operands.
@@ -210,7 +198,8 @@ __device__ __forceinline__ const float4* rec16(const void* base, uint32_t unit) 
     return reinterpret_cast<const float4*>(static_cast<const char*>(base) + ((uint64_t)unit << 4));
 }
 
-// intersect_aabb (shader.wgsl:415-438) with the origin-inside test taken from the signs of the
+// intersect_aabb (shader.wgsl:415-438) on a node record q0 = (min.xyz, max.x), q1 = (max.y,
+// max.z, first, count), with the origin-inside test taken from the signs of the
 // same differences the slab test needs: o >= min  <=>  min - o <= 0, o < max  <=>  max - o > 0
 // (f32 subtraction never flips or drops the sign of an exact non-zero difference).
 __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1) {
