@@ -477,39 +477,50 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 if (__ballot(st == ST_INNER) == 0ull) break;
             }
         } else if (n_leaf >= n_prim) {
-            if (COUNT) r_leaf++;
+            // up to two triangles of the lane's leaf per round (leaves hold 1.8 on average): both
+            // fetches are in flight together and the lane is back among the inner-node lanes a
+            // round earlier
+            const bool two = st == ST_LEAF && cur_count > 1u;
+            if (COUNT) r_leaf += __ballot(two) ? 2u : 1u;
             if (st == ST_LEAF) {
                 const float4* tp = rec16(tris, cur_first * 3u);
                 const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                if (COUNT) c_tri++;
-                float u, v;
-                const float t = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v);
-                if (t >= 0.0f && t < best_t) {
-                    bool accept = true;
-                    if (mode != 0u) { // shader.wgsl:464-487
-                        if (COUNT) c_alpha++;
-                        const PrimX& px = sc.primx[p];
-                        const float b0 = (1.0f - u) - v;
-                        const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
-                        const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)cur_first);
-                        const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
-                        float tcx = 0.0f, tcy = 0.0f;
-                        tcx += b0 * t0.x; tcy += b0 * t0.y;
-                        tcx += u * t1.x;  tcy += u * t1.y;
-                        tcx += v * t2.x;  tcy += v * t2.y;
-                        float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
-                        const uint32_t asize = px.albedo_size;
-                        if (asize != 0u) {
-                            if (COUNT) c_texel++;
-                            alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
+                float4 b0 = a0, b1 = a1, b2 = a2;
+                if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
+                auto test = [&](float4 q0, float4 q1, float4 q2, uint32_t tri_i) {
+                    if (COUNT) c_tri++;
+                    float u, v;
+                    const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
+                    if (t >= 0.0f && t < best_t) {
+                        bool accept = true;
+                        if (mode != 0u) { // shader.wgsl:464-487
+                            if (COUNT) c_alpha++;
+                            const PrimX& px = sc.primx[p];
+                            const float w0 = (1.0f - u) - v;
+                            const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
+                            const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)tri_i);
+                            const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
+                            float tcx = 0.0f, tcy = 0.0f;
+                            tcx += w0 * t0.x; tcy += w0 * t0.y;
+                            tcx += u * t1.x;  tcy += u * t1.y;
+                            tcx += v * t2.x;  tcy += v * t2.y;
+                            float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
+                            const uint32_t asize = px.albedo_size;
+                            if (asize != 0u) {
+                                if (COUNT) c_texel++;
+                                alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
+                            }
+                            if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
+                            else accept = !(rnd(seed) > alpha);
                         }
-                        if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
-                        else accept = !(rnd(seed) > alpha);
+                        if (accept) { best_i = (int32_t)tri_i; best_t = t; }
                     }
-                    if (accept) { best_i = (int32_t)cur_first; best_t = t; }
-                }
-                cur_first++;
-                cur_count--;
+                };
+                test(a0, a1, a2, cur_first);
+                if (two) test(b0, b1, b2, cur_first + 1u);
+                const uint32_t done = two ? 2u : 1u;
+                cur_first += done;
+                cur_count -= done;
                 if (cur_count == 0u) pop_or_finish();
             }
         } else {
