@@ -57,7 +57,9 @@ typedef struct {
     float    aperture_radius;  /* 0.025 world units (camera.aperture is ignored upstream)  */
     uint32_t stack_depth;      /* 23: traversal stack entries; a push beyond it is dropped
                                   and the pixel painted (1,1,0), shader.wgsl:306-313, 941  */
-    uint32_t enable_sun;       /* 0: the live shader has no sun (shader.wgsl:916-937)      */
+    uint32_t enable_sun;       /* 0: the live shader has no sun.  1: the block it keeps
+                                  commented out (shader.wgsl:916-937): a terminated path sends
+                                  one shadow ray (trace_shadow, :528-575) to the sun        */
     uint32_t flags;            /* RTHIP_FLAG_* */
 } rthip_render_params;
 
@@ -86,6 +88,7 @@ typedef struct {
     uint64_t rounds_inner;    /* inner-node steps;      lane steps = inner_steps                */
     uint64_t rounds_leaf;     /* triangle-test steps;   lane steps = tri_tests                  */
     uint64_t batches;         /* 64-ray batches pulled from the queue                           */
+    uint64_t shadow_rays;     /* enable_sun only: trace_shadow calls, shader.wgsl:630-638       */
 } rthip_counters;
 
 #define RTHIP_STAGE_GENERATE 0
@@ -93,7 +96,8 @@ typedef struct {
 #define RTHIP_STAGE_SHADE    2
 #define RTHIP_STAGE_RESOLVE  3
 #define RTHIP_STAGE_ACCUMULATE 4 /* frame-ordered sum of the per-frame results into screen  */
-#define RTHIP_NUM_STAGES     5
+#define RTHIP_STAGE_SHADOW   5   /* enable_sun only: the shadow rays of a bounce             */
+#define RTHIP_NUM_STAGES     6
 
 typedef struct {
     double   ms[RTHIP_NUM_STAGES];        /* summed kernel time per stage, HIP events       */

@@ -82,12 +82,13 @@ struct PathQueue {
 // as the four lanes of one float4 (bit casts).
 
 struct Counters {
-    unsigned long long v[16];
+    unsigned long long v[24];
 };
 enum {
     C_RAYS = 0, C_PRIMS, C_INNER, C_LEAF, C_TRI, C_ALPHA, C_TEXEL, C_SHADE, C_MISS, C_KILL,
     C_OVERFLOW, C_PATHS,
-    C_ROUNDS_PRIM, C_ROUNDS_INNER, C_ROUNDS_LEAF, C_BATCHES   // wave-level: executions of each step kind
+    C_ROUNDS_PRIM, C_ROUNDS_INNER, C_ROUNDS_LEAF, C_BATCHES,  // wave-level: executions of each step kind
+    C_SHADOW                                                   // sun option: shadow rays traced
 };
 
 // ------------------------------------------------------------------ float3 helpers

@@ -591,6 +591,8 @@ struct ShadeArgs {
     const float4* hits;
     const uint32_t* count_in;
     uint32_t* count_out;
+    PathQueue shadow;       // SUN only: shadow rays s0=(o, d.x) s1=(d.y, d.z, seed, slot) s2=(sun term, overflow) s3=(lighting)
+    uint32_t* shadow_count; // SUN only
     float4*   partial;      // one accumulation slot per (frame slot, pixel): written once, by the path's end
     uint32_t* tap_seed;     // null unless taps are on for this launch
     float     term_prob;
@@ -630,9 +632,10 @@ __device__ __forceinline__ f3 linear_rgb(const float* lut, uint32_t x) {
     return F3(lut[(x >> 24) & 255u], lut[(x >> 16) & 255u], lut[(x >> 8) & 255u]);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool SUN>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     __shared__ uint32_t scratch[8];
+    __shared__ uint32_t scratch2[8];
     __shared__ float lin_lut[256];
     lin_lut[threadIdx.x & 255u] = powf((float)(threadIdx.x & 255u) / 255.0f, 2.2f);
     __syncthreads();
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const uint32_t stride = gridDim.x * blockDim.x;
     unsigned long long c_shade = 0, c_miss = 0, c_kill = 0, c_texel = 0;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_pad; slot += stride) {
-        bool survive = false;
+        bool survive = false, to_shadow = false;
         float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
         if (slot < n && __float_as_uint(a.in.s1[slot].w) != RT_NO_PIXEL) {
             const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
@@ -668,6 +671,33 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             } else if (rnd(seed) < a.term_prob) { // shader.wgsl:907-909
                 if (COUNT) c_kill++;
                 thr = thr / a.term_prob;
+                if (SUN) {
+                    // The sun block the reference keeps commented out (shader.wgsl:916-937), as an
+                    // option: a terminated path sends one shadow ray towards the sun.
+                    const PrimitiveD& pr = a.sc.prims[prim];
+                    const float* im = pr.inv_transform;
+                    const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
+                                     (im[2] * dir.x + im[6] * dir.y) + im[10] * dir.z);
+                    const f3 ld = normalize(td);
+                    const float4 a1 = a.sc.tris[3 * (size_t)tri + 1], a2 = a.sc.tris[3 * (size_t)tri + 2];
+                    f3 ng = normalize(cross(F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z)));
+                    ng = ng * (-sign11(dot(ng, ld)));
+                    const f3 n_geo = normalize(F3((im[0] * ng.x + im[1] * ng.y) + im[2] * ng.z, (im[4] * ng.x + im[5] * ng.y) + im[6] * ng.z,
+                                                  (im[8] * ng.x + im[9] * ng.y) + im[10] * ng.z));
+                    const float sl = sqrtf((0.5f * 0.5f + 0.4f * 0.4f) + 1.49f * 1.49f); // TO_SUN_DIR, shader.wgsl:20-24
+                    const f3 sun = F3(0.5f / sl, 0.4f / sl, 1.49f / sl);
+                    const f3 so = origin + (dir * hit_t + n_geo * 0.0001f);
+                    const f3 sd = normalize(sun + rand_sphere(seed) * 0.01f);
+                    const float lambert = fmaxf(dot(sun, n_geo), 0.0f) / RT_PI;
+                    if (lambert > 0.0f) {
+                        const f3 term = ((thr * F3(1.0f * 5.0f, 0.5f * 5.0f, 0.3f * 5.0f)) * 12.0f) * lambert;
+                        to_shadow = true;
+                        o0 = make_float4(so.x, so.y, so.z, sd.x);
+                        o1 = make_float4(sd.y, sd.z, __uint_as_float(seed), __uint_as_float(pix));
+                        o2 = make_float4(term.x, term.y, term.z, overflow ? 1.0f : 0.0f);
+                        o3 = make_float4(lit.x, lit.y, lit.z, 0.0f);
+                    }
+                }
             } else {
                 thr = thr / (1.0f - a.term_prob);
                 // ---- handle_surface_hit_brdf, shader.wgsl:803-881
@@ -770,7 +800,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
                 o3 = make_float4(lit.x, lit.y, lit.z, 0.0f);
             }
 
-            if (!survive) { // the path ends: shader.wgsl:941-946; k_accumulate applies 947-951
+            if (!survive && !to_shadow) { // the path ends: shader.wgsl:941-946; k_accumulate applies 947-951
                 if (overflow) lit = F3(1.0f, 1.0f, 0.0f);
                 a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
                 if (a.tap_seed && pix < a.n_pixels) a.tap_seed[pix] = seed;
@@ -783,6 +813,15 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             a.out.s2[dst] = o2;
             a.out.s3[dst] = o3;
         }
+        if (SUN) {
+            const uint32_t sdst = block_append(to_shadow, a.shadow_count, scratch2);
+            if (to_shadow) {
+                a.shadow.s0[sdst] = o0;
+                a.shadow.s1[sdst] = o1;
+                a.shadow.s2[sdst] = o2;
+                a.shadow.s3[sdst] = o3;
+            }
+        }
     }
     if (COUNT) {
         const unsigned long long s0 = wave_sum(c_shade), s1 = wave_sum(c_miss), s2 = wave_sum(c_kill), s3 = wave_sum(c_texel);
@@ -792,6 +831,97 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             if (s2) atomicAdd(&a.counters[C_KILL], s2);
             if (s3) atomicAdd(&a.counters[C_TEXEL], s3);
         }
+    }
+}
+
+// ------------------------------------------------------------------ shadow (sun option)
+
+struct ShadowArgs {
+    SceneDev  sc;
+    PathQueue in;           // shadow rays written by k_shade<., true>
+    const uint32_t* count;
+    float4*   partial;
+    uint32_t* tap_seed;     // null unless taps are on for this launch
+    uint32_t  stack_depth;
+    uint32_t  n_pixels;
+    unsigned long long* counters; // null unless counting
+};
+
+// trace_shadow / trace_bvh_shadow, shader.wgsl:528-575, 630-638: does anything lie along the ray?
+// Every primitive in index order until the first triangle with t >= 0; no alpha test, no
+// distance bound, near child first, an overflowing push is dropped.  One lane per shadow ray with
+// a private stack: this is the opt-in path, written for clarity rather than for the last cycle.
+// Primitives whose padded world bound the ray misses are skipped (they cannot occlude).
+// The path then ends: lighting (+ the sun term if nothing occludes) goes to its result slot.
+__global__ __launch_bounds__(256) void k_shadow(ShadowArgs a) {
+    const uint32_t n = *a.count;
+    const SceneDev& sc = a.sc;
+    const uint32_t depth = min(a.stack_depth, RT_MAX_STACK);
+    unsigned long long c_shadow = 0;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
+        const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
+        const uint32_t pix = __float_as_uint(s1.w);
+        c_shadow++;
+        const f3 r = rcp3(d);
+        const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
+        const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+        bool occluded = false;
+        uint32_t stack[RT_MAX_STACK];
+        for (uint32_t p = 0; p < sc.n_prims && !occluded; p++) {
+            const float* wb = sc.wbounds + (size_t)(p >> 3) * 48u + (p & 7u);
+            const float b[6] = {wb[0], wb[8], wb[16], wb[24], wb[32], wb[40]};
+            if (!overlaps_world_box(oi, idir, b)) continue;
+            const PrimX& px = sc.primx[p];
+            const f3 td = xform_dir(d, px.inv);
+            const f3 ld = td / length(td);
+            const f3 lo = xform_pos(o, px.inv);
+            const f3 lidir = rcp3(ld);
+            const float4* rp = reinterpret_cast<const float4*>(px.root_box);
+            if (hit_aabb_s(lo, lidir, rp[0], rp[1]) < -0.5f) continue;
+            uint32_t first = px.root_first, count = px.root_count, sp = 0;
+            for (;;) {
+                if (count > 0u) {
+                    for (uint32_t i = first; i < first + count && !occluded; i++) {
+                        const float4* tp = rec16(sc.tris, i * 3u);
+                        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                        float u, v;
+                        occluded = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v) >= 0.0f;
+                    }
+                    if (occluded || sp == 0u) break;
+                    const float4 q = rec16(sc.nodes, stack[--sp] * 2u)[1];
+                    first = __float_as_uint(q.z);
+                    count = __float_as_uint(q.w);
+                } else {
+                    const float4* np = rec16(sc.nodes, first * 2u);
+                    const float4 l0 = np[0], l1 = np[1], q0 = np[2], q1 = np[3];
+                    const float left = hit_aabb_s(lo, lidir, l0, l1);
+                    const float right = hit_aabb_s(lo, lidir, q0, q1);
+                    const bool lmiss = left < -0.5f, rmiss = right < -0.5f;
+                    if (lmiss && rmiss) {
+                        if (sp == 0u) break;
+                        const float4 q = rec16(sc.nodes, stack[--sp] * 2u)[1];
+                        first = __float_as_uint(q.z);
+                        count = __float_as_uint(q.w);
+                    } else {
+                        const bool go_left = rmiss ? true : (lmiss ? false : left < right);
+                        if (!lmiss && !rmiss && sp < depth) stack[sp++] = go_left ? first + 1u : first;
+                        const float4 c = go_left ? l1 : q1;
+                        first = __float_as_uint(c.z);
+                        count = __float_as_uint(c.w);
+                    }
+                }
+            }
+        }
+        f3 lit = F3(s3.x, s3.y, s3.z);
+        if (!occluded) lit = lit + F3(s2.x, s2.y, s2.z);
+        if (s2.w != 0.0f) lit = F3(1.0f, 1.0f, 0.0f); // a dropped push on the camera path, shader.wgsl:941-943
+        a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
+        if (a.tap_seed && pix < a.n_pixels) a.tap_seed[pix] = __float_as_uint(s1.z);
+    }
+    if (a.counters) {
+        const unsigned long long sum = wave_sum(c_shadow);
+        if (lane_id() == 0 && sum) atomicAdd(&a.counters[C_SHADOW], sum);
     }
 }
 

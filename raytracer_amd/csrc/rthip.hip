@@ -74,10 +74,12 @@ struct rthip_ctx {
     std::vector<uint32_t> prim_roots;
     std::map<uint32_t, NanWalk> nan_walks; // by stack depth
     float4*   partial = nullptr;
+    float4*   shadow_mem = nullptr; // sun option: shadow-ray queue (4 planes of queue_cap), allocated on first use
+    uint64_t  shadow_cap = 0;
     uint32_t* spill = nullptr;      // deep-stack columns (levels beyond the LDS part), allocated on first use
     uint64_t  spill_words = 0;    // frames_cap x n_pixels accumulation slots
     uint32_t  frames_cap = 0;       // frames one launch group can hold
-    uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors
+    uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors, [128..191] shadow-ray counts
     int32_t*  tap_tri = nullptr;
     int32_t*  tap_prim = nullptr;
     float*    tap_t = nullptr;
@@ -137,7 +139,8 @@ void free_scene(rthip_ctx* c) {
 }
 
 void free_frame_buffers(rthip_ctx* c) {
-    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill);
+    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
+    c->shadow_cap = 0;
     c->spill_words = 0;
     c->frames_cap = 0;
     free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
@@ -304,7 +307,7 @@ int rthip_create(int device_ordinal, rthip_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, RTHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc((void**)&c->ctrl, sizeof(uint32_t) * 128);
+    e = hipMalloc((void**)&c->ctrl, sizeof(uint32_t) * 256);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(Counters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(Counters));
     if (e != hipSuccess) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -599,7 +602,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     if (P.max_bounces == 0 || P.max_bounces > 63) return fail(c, RTHIP_ERR_INVALID, "render: max_bounces %u outside 1..63", P.max_bounces);
     if (!(P.term_prob >= 0.0f && P.term_prob < 1.0f)) return fail(c, RTHIP_ERR_INVALID, "render: term_prob %g outside [0,1)", (double)P.term_prob);
     if (P.stack_depth == 0 || P.stack_depth > RTHIP_MAX_STACK_DEPTH) return fail(c, RTHIP_ERR_INVALID, "render: stack_depth %u outside 1..%u", P.stack_depth, RTHIP_MAX_STACK_DEPTH);
-    if (P.enable_sun) return fail(c, RTHIP_ERR_UNSUPPORTED, "render: the sun extension is not built into this library");
+    if (P.enable_sun > 1) return fail(c, RTHIP_ERR_INVALID, "render: enable_sun %u is neither 0 nor 1", P.enable_sun);
     uint32_t prim_count;
     std::memcpy(&prim_count, c->uniforms + 600, 4);
     if (prim_count != c->sc.n_prims) return fail(c, RTHIP_ERR_INVALID, "render: uniforms say %u primitives, scene has %u", prim_count, c->sc.n_prims);
@@ -667,6 +670,13 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const uint32_t nf = std::min(group, n_frames - f0);
         const uint64_t slots = (uint64_t)ga.n_tiles * 64 * nf;
         const uint32_t ext_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * ext_blocks, (slots + 255) / 256);
+        if (P.enable_sun && c->shadow_cap < c->queue_cap) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            free_dev_t(c->shadow_mem);
+            c->shadow_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->shadow_mem, sizeof(float4) * 4 * c->queue_cap));
+            c->shadow_cap = c->queue_cap;
+        }
         if (deep) { // stack levels beyond the LDS part: one dword column per thread of the extend grid
             const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_LDS_LEVELS) * ext_grid * 256;
             if (c->spill_words < words) {
@@ -681,7 +691,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const uint32_t gen_grid = (uint32_t)((slots + 255) / 256);
         const bool overwrite = (c->reject_hist == 1);
         const bool tap_group = taps && f0 == 0;
-        HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 128, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 256, c->stream));
         ga.out = q[0];
         ga.count_out = c->ctrl;
         ga.first_frame = first_frame + f0 * frame_stride;
@@ -735,8 +745,30 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             sa.counters = c->d_counters;
             {
                 StageTimer t(c, timing, RTHIP_STAGE_SHADE);
-                if (count) hipLaunchKernelGGL((k_shade<true>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
-                else hipLaunchKernelGGL((k_shade<false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+                if (P.enable_sun) {
+                    const uint64_t cap = c->shadow_cap;
+                    sa.shadow.s0 = c->shadow_mem; sa.shadow.s1 = c->shadow_mem + cap;
+                    sa.shadow.s2 = c->shadow_mem + 2 * cap; sa.shadow.s3 = c->shadow_mem + 3 * cap;
+                    sa.shadow_count = c->ctrl + 128 + b;
+                    if (count) hipLaunchKernelGGL((k_shade<true, true>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+                    else hipLaunchKernelGGL((k_shade<false, true>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+                } else {
+                    if (count) hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+                    else hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(256), 0, c->stream, sa);
+                }
+            }
+            if (P.enable_sun) {
+                ShadowArgs wa{};
+                wa.sc = c->sc;
+                wa.in = sa.shadow;
+                wa.count = c->ctrl + 128 + b;
+                wa.partial = c->partial;
+                wa.tap_seed = tap_group ? c->tap_seed : nullptr;
+                wa.stack_depth = P.stack_depth;
+                wa.n_pixels = (uint32_t)c->n_pixels;
+                wa.counters = count ? c->d_counters : nullptr;
+                StageTimer t(c, timing, RTHIP_STAGE_SHADOW);
+                hipLaunchKernelGGL(k_shadow, dim3(shade_grid), dim3(256), 0, c->stream, wa);
             }
         }
         {
@@ -892,6 +924,7 @@ int rthip_get_counters(rthip_ctx* c, rthip_counters* out) {
     out->kills = h.v[C_KILL]; out->stack_overflows = h.v[C_OVERFLOW]; out->paths = h.v[C_PATHS];
     out->rounds_prim = h.v[C_ROUNDS_PRIM]; out->rounds_inner = h.v[C_ROUNDS_INNER]; out->rounds_leaf = h.v[C_ROUNDS_LEAF];
     out->batches = h.v[C_BATCHES];
+    out->shadow_rays = h.v[C_SHADOW];
     return RTHIP_OK;
 }
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
 FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
-STAGES = ("generate", "extend", "shade", "resolve", "accumulate")
+STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "shadow")
 
 EXPORTS = (
     "rthip_device_count", "rthip_create", "rthip_destroy", "rthip_last_error", "rthip_set_stream",
@@ -54,7 +54,7 @@ class RenderParams(C.Structure):
 
 COUNTER_NAMES = ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests",
                  "texel_fetches", "shade_calls", "misses", "kills", "stack_overflows", "paths",
-                 "rounds_prim", "rounds_inner", "rounds_leaf", "batches")
+                 "rounds_prim", "rounds_inner", "rounds_leaf", "batches", "shadow_rays")
 
 
 class CountersStruct(C.Structure):

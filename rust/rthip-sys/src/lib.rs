@@ -57,6 +57,7 @@ pub struct rthip_counters {
     pub rounds_inner: u64,
     pub rounds_leaf: u64,
     pub batches: u64,
+    pub shadow_rays: u64,
 }
 
 pub const RTHIP_FLAG_COUNTERS: u32 = 1;

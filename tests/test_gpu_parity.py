@@ -190,6 +190,26 @@ def test_nan_direction_rays_match_oracle(ctx, scenes, depth):
     np.testing.assert_array_equal(got["accum"], ref["accum"])
 
 
+@pytest.mark.parametrize("name,res", [("materials", (160, 96)), ("blob", (96, 96))])
+def test_sun_option_matches_oracle(ctx, scenes, name, res):
+    """enable_sun = 1: the block the reference keeps commented out (shader.wgsl:916-937); a
+    terminated path sends one shadow ray (trace_shadow, :528-575) to the sun."""
+    s, a = scenes[name]
+    p = device.default_params(max_bounces=4)
+    p.enable_sun = 1
+    got, ref = run_both(ctx, s, a, res, n_frames=4, params=p)
+    assert ref["counters"]["shadow_rays"] > 0
+    assert abs(got["counters"]["shadow_rays"] - ref["counters"]["shadow_rays"]) <= max(4, 2e-3 * ref["counters"]["shadow_rays"])
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.9995
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.995
+    assert np.array_equal(got["accum"][..., 3], ref["accum"][..., 3])
+    assert psnr(tonemapped(got["accum"]), tonemapped(ref["accum"])) >= 45.0
+    # the sun must actually light something
+    p.enable_sun = 0
+    dark, _ = run_both(ctx, s, a, res, n_frames=4, params=p)
+    assert float(got["accum"][..., :3].sum()) > float(dark["accum"][..., :3].sum()) * 1.02
+
+
 def test_errors_are_reported_not_thrown(scenes):
     c = device.Context(0)
     with pytest.raises(device.RtHipError) as e:
