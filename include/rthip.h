@@ -168,6 +168,17 @@ int rthip_read_tri_order(rthip_ctx* ctx, uint32_t* out, uint64_t n_tris);
 /* The device triangle records (48 bytes each: p0.xyz,0, e1.xyz,0, e2.xyz,0). */
 int rthip_read_tris_device_layout(rthip_ctx* ctx, void* out, uint64_t n_tris);
 
+/* trace() (shader.wgsl:598-627) for caller-supplied rays: the closest hit of each of n rays
+ * through every primitive, exactly as a path segment finds it.  rays6 holds origin.xyz and
+ * direction.xyz per ray (world space; the direction is used as given).  seeds (may be NULL: all
+ * zero) are the RNG states the BLEND alpha test draws from and come back advanced.  Outputs (any
+ * may be NULL): distance (99999999 on a miss), triangle index (-1 on a miss), primitive index,
+ * and 1 where a traversal-stack push was dropped.  Scene::focus_camera (scene.rs:670-677) is one
+ * such ray.  Synchronous. */
+int rthip_trace_rays(rthip_ctx* ctx, const float* rays6, uint32_t* seeds, uint64_t n,
+                     const rthip_render_params* params, float* t, int32_t* tri_idx,
+                     int32_t* prim_idx, uint8_t* overflow);
+
 /* The render pass of frame() (main.rs:395-401; fs_main, shader.wgsl:994-1012): mean, PBR
  * Neutral tonemap, then the linear->sRGB transfer the reference gets from its sRGB surface
  * (main.rs:116) when apply_srgb_oetf != 0, rounded to 8 bits; alpha = 255. */

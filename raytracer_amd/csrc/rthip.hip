@@ -792,6 +792,98 @@ int rthip_reserve(rthip_ctx* c, uint32_t n_frames) {
     return ensure_frame_buffers(c, std::min<uint32_t>(n_frames, frames_in_flight_limit(c)));
 }
 
+int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t n, const rthip_render_params* params,
+                     float* t, int32_t* tri_idx, int32_t* prim_idx, uint8_t* overflow) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "trace_rays: no scene uploaded");
+    if (n == 0) return RTHIP_OK;
+    if (!rays6) return fail(c, RTHIP_ERR_INVALID, "trace_rays: null rays");
+    if (n >= 0x7FFFFFFFull) return fail(c, RTHIP_ERR_INVALID, "trace_rays: more than 2^31-1 rays");
+    rthip_render_params P;
+    if (params) P = *params; else rthip_default_params(&P);
+    if (P.stack_depth == 0 || P.stack_depth > RTHIP_MAX_STACK_DEPTH) return fail(c, RTHIP_ERR_INVALID, "trace_rays: stack_depth %u outside 1..%u", P.stack_depth, RTHIP_MAX_STACK_DEPTH);
+    DeviceGuard g(c->device);
+
+    // the rays as the first two planes of a path queue
+    std::vector<float> planes((size_t)n * 8);
+    for (uint64_t i = 0; i < n; i++) {
+        float* s0 = &planes[(size_t)i * 4];
+        float* s1 = &planes[(size_t)(n + i) * 4];
+        const float* r = rays6 + i * 6;
+        s0[0] = r[0]; s0[1] = r[1]; s0[2] = r[2]; s0[3] = r[3];
+        s1[0] = r[4]; s1[1] = r[5];
+        const uint32_t seed = seeds ? seeds[i] : 0u, slot = 0u;
+        std::memcpy(&s1[2], &seed, 4);
+        std::memcpy(&s1[3], &slot, 4);
+    }
+    float4* d_q = nullptr;
+    float4* d_hits = nullptr;
+    uint32_t* d_ctl = nullptr; // [0] = ray count, [1] = cursor
+    auto cleanup = [&]() { free_dev_t(d_q); free_dev_t(d_hits); free_dev_t(d_ctl); };
+    hipError_t e = hipMalloc((void**)&d_q, sizeof(float4) * 2 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_hits, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ctl, sizeof(uint32_t) * 2);
+    const uint32_t ctl[2] = {(uint32_t)n, 0u};
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, planes.data(), sizeof(float4) * 2 * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e)); }
+
+    const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
+    const bool deep = P.stack_depth > RT_LDS_LEVELS;
+    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
+    const int blocks = deep ? occupancy_blocks(k_extend<false, true>, 256) : occupancy_blocks(k_extend<false, false>, 256);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * blocks, (n + 255) / 256);
+    if (deep) {
+        const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_LDS_LEVELS) * grid * 256;
+        if (c->spill_words < words) {
+            (void)hipStreamSynchronize(c->stream);
+            free_dev_t(c->spill);
+            c->spill_words = 0;
+            e = hipMalloc((void**)&c->spill, sizeof(uint32_t) * words);
+            if (e != hipSuccess) { cleanup(); return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e)); }
+            c->spill_words = words;
+        }
+    }
+    ExtArgs ea{};
+    ea.sc = c->sc;
+    ea.in.s0 = d_q; ea.in.s1 = d_q + n; ea.in.s2 = d_q; ea.in.s3 = d_q;
+    ea.hits = d_hits;
+    ea.spill = c->spill;
+    ea.count_in = d_ctl;
+    ea.cursor = d_ctl + 1;
+    ea.stack_depth = P.stack_depth;
+    ea.counters = c->d_counters;
+    ea.nan_inner = nanw.inner; ea.nan_leaf = nanw.leaf; ea.nan_tri = nanw.tri; ea.nan_dropped = nanw.dropped;
+    ea.nan_overflow = nanw.dropped ? 1u : 0u;
+    if (count) {
+        if (deep) hipLaunchKernelGGL((k_extend<true, true>), dim3(grid), dim3(256), 0, c->stream, ea);
+        else hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), 0, c->stream, ea);
+    } else {
+        if (deep) hipLaunchKernelGGL((k_extend<false, true>), dim3(grid), dim3(256), 0, c->stream, ea);
+        else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), 0, c->stream, ea);
+    }
+    std::vector<float> hits((size_t)n * 4);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hits.data(), d_hits, sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
+    for (uint64_t i = 0; i < n; i++) {
+        const float* h = &hits[(size_t)i * 4];
+        int32_t tri;
+        uint32_t primw, seed;
+        std::memcpy(&tri, &h[1], 4);
+        std::memcpy(&primw, &h[2], 4);
+        std::memcpy(&seed, &h[3], 4);
+        if (t) t[i] = h[0];
+        if (tri_idx) tri_idx[i] = tri;
+        if (prim_idx) prim_idx[i] = tri >= 0 ? (int32_t)(primw & 0x7FFFFFFFu) : -1;
+        if (overflow) overflow[i] = (uint8_t)(primw >> 31);
+        if (seeds) seeds[i] = seed;
+    }
+    return RTHIP_OK;
+}
+
 int rthip_bind_accum(rthip_ctx* c, void* device_ptr, uint64_t n_pixels) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     DeviceGuard g(c->device);

@@ -24,7 +24,7 @@ EXPORTS = (
     "rthip_read_taps", "rthip_read_nodes_device_layout", "rthip_read_node_index_map",
     "rthip_read_tri_order", "rthip_read_tris_device_layout", "rthip_resolve",
     "rthip_get_counters", "rthip_reset_counters", "rthip_get_timing", "rthip_reset_timing",
-    "rthip_synchronize", "rthip_copy_bandwidth",
+    "rthip_synchronize", "rthip_copy_bandwidth", "rthip_trace_rays",
 )
 
 
@@ -87,6 +87,7 @@ def lib():
         l.rthip_set_frame_uniforms.argtypes = [vp, vp]
         l.rthip_default_params.argtypes = [C.POINTER(RenderParams)]
         l.rthip_reserve.argtypes = [vp, C.c_uint32]
+        l.rthip_trace_rays.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_copy_bandwidth.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
         l.rthip_default_params.restype = None
         l.rthip_render.argtypes = [vp, u32, u32, u32, C.POINTER(RenderParams)]
@@ -187,6 +188,22 @@ class Context:
     def render(self, first_frame=1, n_frames=1, frame_stride=1, params=None):
         p = params or default_params()
         self._check(lib().rthip_render(self._h, first_frame, n_frames, frame_stride, C.byref(p)))
+
+    def trace_rays(self, origins, directions, seeds=None, params=None):
+        """trace() (shader.wgsl:598-627) for arbitrary rays.  Returns dict(t, tri, prim, overflow, seed)."""
+        o = np.asarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.asarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        n = o.shape[0]
+        rays = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+        sd = np.zeros(n, np.uint32) if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32).copy()
+        t = np.zeros(n, np.float32)
+        tri = np.zeros(n, np.int32)
+        prim = np.zeros(n, np.int32)
+        ovf = np.zeros(n, np.uint8)
+        p = params or default_params()
+        self._check(lib().rthip_trace_rays(self._h, _p(rays), _p(sd), n, C.byref(p), _p(t), _p(tri), _p(prim), _p(ovf)))
+        return dict(t=t, tri=tri, prim=prim, overflow=ovf, seed=sd)
 
     def reserve(self, n_frames):
         """Allocate the work buffers for calls of up to n_frames frames ahead of the first render."""

@@ -76,6 +76,8 @@ extern "C" {
     pub fn rthip_render(ctx: *mut rthip_ctx, first_frame: u32, n_frames: u32, frame_stride: u32,
                         params: *const rthip_render_params) -> c_int;
     pub fn rthip_reserve(ctx: *mut rthip_ctx, n_frames: u32) -> c_int;
+    pub fn rthip_trace_rays(ctx: *mut rthip_ctx, rays6: *const f32, seeds: *mut u32, n: u64, params: *const rthip_render_params,
+                            t: *mut f32, tri_idx: *mut i32, prim_idx: *mut i32, overflow: *mut u8) -> c_int;
     pub fn rthip_copy_bandwidth(ctx: *mut rthip_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;
     pub fn rthip_bind_accum(ctx: *mut rthip_ctx, device_ptr: *mut c_void, n_pixels: u64) -> c_int;
     pub fn rthip_accum_device_ptr(ctx: *mut rthip_ctx, device_ptr: *mut *mut c_void, n_pixels: *mut u64) -> c_int;

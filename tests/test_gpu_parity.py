@@ -226,3 +226,36 @@ def test_errors_are_reported_not_thrown(scenes):
     with pytest.raises(device.RtHipError):
         device.Context(99)
     c.close()
+
+
+def test_ray_queries_match_oracle_bit_for_bit(ctx, scenes):
+    """rthip_trace_rays against the oracle's trace(), ray by ray: random rays, axis-parallel
+    directions (zero components), unnormalised and tiny directions, origins far outside, NaN
+    directions, and a stack too short for the tree."""
+    s, a = scenes["materials"]
+    ctx.upload_scene(a)
+    sc = oracle_scene(a)
+    rng = np.random.default_rng(7)
+    n = 600
+    o = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:60] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 60)] * rng.choice([-1.0, 1.0], (60, 1)).astype(np.float32)
+    d[60:90] *= 7.5                       # not normalised
+    d[90:110] *= 1e-20                    # nearly degenerate
+    o[110:130] = o[110:130] * 1e4         # far away
+    d[110:130] = -o[110:130] / np.linalg.norm(o[110:130], axis=1, keepdims=True)   # aimed at the scene
+    d[130:134] = np.nan
+    d[134] = (0.0, 0.0, 0.0)
+    seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    for depth in (23, 2, 40):
+        p = device.default_params(stack_depth=depth)
+        got = ctx.trace_rays(o, d, seeds, p)
+        op = oracle_params(p)
+        for i in range(n):
+            tri, prim, t, seed = orc.trace_ray(sc, o[i], d[i], op, int(seeds[i]))
+            assert got["tri"][i] == tri, (depth, i)
+            if tri >= 0:
+                assert got["prim"][i] == prim, (depth, i)
+                assert got["t"][i] == np.float32(t), (depth, i)
+            assert got["seed"][i] == seed, (depth, i)
