@@ -33,6 +33,30 @@ def extend_algorithmic_bytes(c):
     return (32 * (c["prims_visited"] + 2 * c["inner_steps"]) + 36 * c["tri_tests"] + 80 * c["prims_visited"])
 
 
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_extend_summary.txt")
+
+
+def profiled_extend_traffic():
+    """HBM-side bytes per k_extend launch from the committed rocprofv3 PMC passes of this same
+    default command (tools/prof.sh): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+    tallies 128-byte requests at 64 bytes, so it is doubled.  None when the summary is missing."""
+    try:
+        text = open(PROFILE_SUMMARY).read()
+    except OSError:
+        return None
+    block = text.split("\n  void k_extend<false, false>(ExtArgs)\n")
+    if len(block) < 2:
+        return None
+    vals = {}
+    for line in block[-1].split("\n\n")[0].splitlines():
+        f = line.split()
+        if len(f) >= 5 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[f[0]] = float(f[-1])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def build_workload(args):
     if args.workload == "atrium":
         scene = procedural.atrium_scene(detail=args.detail, tex=args.tex)
@@ -173,6 +197,8 @@ def main():
         rays_total = int(rt.item())
 
     copy_gbs = ctx.copy_bandwidth() if rank == 0 else 0.0
+    default_run = (args.workload == "atrium" and args.res == "1920x1080" and args.max_bounces == 4 and args.detail == 1.0
+                   and args.tex == 1024 and K % 32 == 0 and not args.opaque and os.environ.get("RTHIP_FRAMES_IN_FLIGHT") is None)
     if rank == 0:
         ext = timing["extend"]
         ext_bytes = extend_algorithmic_bytes(counters)
@@ -215,7 +241,10 @@ def main():
                 "peak_stream_copy": round(copy_gbs, 1),
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                # PMC counters cannot be read from inside the run; this is the figure of the committed
+                # profile of the default command (same workload, same 32-frame launches)
+                "traffic": profiled_extend_traffic() if default_run else None,
+                "traffic_source": "profiles/r01_final_extend_summary.txt" if default_run else None,
                 "launches": ext["launches"],
                 "avg_launch_ms": round(avg_ms, 5),
                 "algorithmic_bytes_per_launch": round(ext_bytes / launches, 1),
