@@ -58,6 +58,13 @@ def profiled_extend_traffic():
 
 
 def build_workload(args):
+    if args.scene:
+        # a baked scene (e.g. Khronos Sponza prepared elsewhere); its own first camera is used
+        from raytracer_amd import host
+        scene = host.Scene.from_cache(args.scene)
+        if scene.n_cameras == 0:
+            scene.add_camera(host.Camera.default())
+        return scene, f"baked scene {os.path.basename(args.scene)}"
     if args.workload == "atrium":
         scene = procedural.atrium_scene(detail=args.detail, tex=args.tex)
         name = "sponza-proxy atrium (procedural; Khronos Sponza is not shipped with the reference)"
@@ -101,6 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="atrium")
+    ap.add_argument("--scene", default=None, help="path of a .rtscene file to render instead of a procedural workload")
     ap.add_argument("--res", default="1920x1080")
     ap.add_argument("--max-bounces", type=int, default=4)
     ap.add_argument("--term-prob", type=float, default=0.5)
@@ -197,7 +205,7 @@ def main():
         rays_total = int(rt.item())
 
     copy_gbs = ctx.copy_bandwidth() if rank == 0 else 0.0
-    default_run = (args.workload == "atrium" and args.res == "1920x1080" and args.max_bounces == 4 and args.detail == 1.0
+    default_run = (args.scene is None and args.workload == "atrium" and args.res == "1920x1080" and args.max_bounces == 4 and args.detail == 1.0
                    and args.tex == 1024 and K % 32 == 0 and not args.opaque and os.environ.get("RTHIP_FRAMES_IN_FLIGHT") is None)
     if rank == 0:
         ext = timing["extend"]

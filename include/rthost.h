@@ -99,6 +99,14 @@ int rthost_scene_load_gltf(rthost_scene* s, const void* bytes, size_t n_bytes,
 int rthost_scene_load_gltf_file(rthost_scene* s, const char* path);
 int rthost_scene_load_hdr_file(rthost_scene* s, const char* path);
 
+/* .rtscene cache: every flat array of the scene (and its cameras) in one file, written once and
+ * then only read.  For scenes whose source needs a decoder this build lacks (JPEG textures) or
+ * that take long to build; the reference's Rust host can write the same file because its Vecs
+ * hold the same bytes (scene.rs:239-251).  load_cache replaces the scene's content and refuses
+ * files whose lengths or tree indices are inconsistent.  Layout: csrc/host/cache.cpp. */
+int rthost_scene_save(const rthost_scene* s, const char* path);
+int rthost_scene_load_cache(rthost_scene* s, const char* path);
+
 /* Cameras (input.rs:34-51, 202-253).  A camera is yaw/pitch/roll + position + fovy + focus. */
 typedef struct {
     float yaw, pitch, roll;

@@ -80,3 +80,6 @@ bool decode_hdr(const uint8_t* bytes, size_t n, std::vector<float>& rgba32f, uin
 bool read_file(const std::string& path, std::vector<uint8_t>& out);
 
 } // namespace rthost
+
+// the opaque handle of the C ABI
+struct rthost_scene { rthost::Scene s; };

@@ -308,8 +308,6 @@ static bool scene_closest_hit(const Scene& s, const float ro_w[3], const float r
 
 using namespace rthost;
 
-struct rthost_scene { Scene s; };
-
 extern "C" {
 
 const char* rthost_last_error(void) { return g_error.c_str(); }

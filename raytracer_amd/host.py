@@ -65,6 +65,8 @@ def lib():
         l.rthost_scene_load_gltf.argtypes = [vp, vp, C.c_size_t, C.c_char_p]
         l.rthost_scene_load_gltf_file.argtypes = [vp, C.c_char_p]
         l.rthost_scene_load_hdr_file.argtypes = [vp, C.c_char_p]
+        l.rthost_scene_save.argtypes = [vp, C.c_char_p]
+        l.rthost_scene_load_cache.argtypes = [vp, C.c_char_p]
         l.rthost_camera_default.argtypes = [C.POINTER(CameraStruct)]
         l.rthost_camera_default.restype = None
         l.rthost_camera_to_gpu.argtypes = [C.POINTER(CameraStruct), vp]
@@ -183,6 +185,17 @@ class Scene:
         if s.n_cameras == 0:
             s.add_camera(Camera.default())
         return s
+
+    @classmethod
+    def from_cache(cls, path):
+        """A scene written by save() (or by the reference's host in the same layout)."""
+        s = cls()
+        _check(lib().rthost_scene_load_cache(s._h, os.fsencode(path)))
+        return s
+
+    def save(self, path):
+        """Write the flat arrays and cameras as one .rtscene file."""
+        _check(lib().rthost_scene_save(self._h, os.fsencode(path)))
 
     def add_gltf_bytes(self, data, base_dir="."):  # scene.rs:268-284
         buf = np.frombuffer(data, dtype=np.uint8)

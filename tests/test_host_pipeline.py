@@ -191,3 +191,40 @@ def test_focus_camera_casts_along_forward():
     s2.add_primitive(pos, idx, transform=host.trs((0, 50, 0)))
     s2.add_camera(host.Camera.default())
     assert not s2.focus_camera(0) and s2.camera(0).c.focus == 1.0
+
+
+def test_scene_cache_round_trip(tmp_path):
+    """.rtscene: every array and camera comes back byte for byte; damaged files are refused."""
+    from raytracer_amd import host, procedural
+    s = procedural.material_test_scene(tex=16, env_size=(32, 16))
+    path = str(tmp_path / "m.rtscene")
+    s.save(path)
+    t = host.Scene.from_cache(path)
+    a, b = s.arrays(), t.arrays()
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert t.n_cameras == s.n_cameras
+    u0 = np.ascontiguousarray(s.frame_uniforms((64, 48), frame=3)).tobytes()
+    u1 = np.ascontiguousarray(t.frame_uniforms((64, 48), frame=3)).tobytes()
+    assert u0 == u1
+    raw = bytearray(open(path, "rb").read())
+    # truncated
+    open(path, "wb").write(raw[:-16])
+    with pytest.raises(host.RtHostError):
+        host.Scene.from_cache(path)
+    # wrong magic
+    bad = bytearray(raw)
+    bad[0:8] = b"NOTSCENE"
+    open(path, "wb").write(bad)
+    with pytest.raises(host.RtHostError):
+        host.Scene.from_cache(path)
+    # a node that points outside the node array: first inner node's `first` field
+    nodes = a["nodes"]
+    inner = int(np.flatnonzero(nodes["count"] == 0)[0])
+    off = 64 + ((48 * a["tris"].shape[0] + 15) & ~15) + ((96 * a["tris"].shape[0] + 15) & ~15) + 32 * inner + 24
+    bad = bytearray(raw)
+    bad[off:off + 4] = np.array([0x7FFFFFF0], np.uint32).tobytes()
+    open(path, "wb").write(bad)
+    with pytest.raises(host.RtHostError):
+        host.Scene.from_cache(path)
