@@ -72,8 +72,8 @@ def build_workload(args):
         scene = procedural.blob_scene()
         name = "suzanne-proxy blob"
     elif args.workload == "terrain":
-        scene = procedural.terrain_scene(tiles=args.tiles, n=args.terrain_n)
-        name = f"terrain tiled {args.tiles}x{args.tiles}"
+        scene = procedural.terrain_scene(tiles=args.tiles, n=args.terrain_n, instanced=args.instanced)
+        name = f"terrain tiled {args.tiles}x{args.tiles}" + (" as instances" if args.instanced else "")
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     return scene, name
@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--tex", type=int, default=1024)
     ap.add_argument("--tiles", type=int, default=1)
     ap.add_argument("--terrain-n", type=int, default=60)
+    ap.add_argument("--instanced", action="store_true", help="terrain tiles as instanced primitives instead of one merged BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opaque", action="store_true", help="diagnostic: treat MASK/BLEND materials as opaque")
     ap.add_argument("--first-frame", type=int, default=1, help="frame index of the first timed step (RNG key)")

@@ -58,6 +58,10 @@ struct SceneDev {
     // read through the scalar cache); the slots past the last primitive are padding whose
     // result the scan discards
     const float*      wbounds;
+    // union bounds (min.xyz, max.xyz, 0, 0: 32 bytes each) of every group of eight primitives
+    // and of every chunk of 128, for scenes of more than one chunk
+    const float*      gbounds;
+    const float*      cbounds;
     const PrimitiveD* prims;
     const uint32_t*   texels;
     const float4*     env;
@@ -65,6 +69,8 @@ struct SceneDev {
     uint32_t          env_w, env_h;
     uint32_t          n_prims;
     uint32_t          n_prim_groups;  // ceil(n_prims / 8)
+    uint32_t          n_chunks;       // ceil(n_prims / 128)
+    uint32_t          pad;
 };
 
 // Path state: four float4 streams per queue slot, so every access is a 16-byte-per-lane,

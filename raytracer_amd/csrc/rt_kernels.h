@@ -236,6 +236,10 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // are waiting, the waiting lanes take the next reserved slots.  No lane idles until the
 // slowest ray of a batch is done.
 //
+// MULTI instantiation (scenes of more than 128 primitives): every chunk of 128 and every group
+// of eight primitives also has a union bound; a new ray first learns which chunks it can touch
+// at all (cmask), and the scan of a chunk skips the groups that no waiting lane's ray meets.
+//
 // Candidate primitives come from a wave-uniform scan of padded world-space bounds (scalar
 // loads of eight primitives' bounds at a time), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
 // bound the ray misses changes nothing the reference would compute.
@@ -244,7 +248,7 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // the first RT_LDS_LEVELS entries; the DEEP instantiation (stack_depth above that, for trees of
 // tens of millions of triangles) continues in a global-memory column per thread, so that a deep
 // stack does not cost occupancy.  The reference does not re-test the box of a popped node either.
-template <bool COUNT, bool DEEP>
+template <bool COUNT, bool DEEP, bool MULTI>
 __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
     const uint32_t lane = lane_id();
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
     bool overflow = false;
     uint32_t mask[4] = {0, 0, 0, 0};
     uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes
+    unsigned long long cmask = ~0ull; // bit c: the ray meets the union bound of chunk c (c < 64)
     uint32_t p = 0, cur_first = 0, cur_count = 0, sp = 0, mode = 0;
     f3 lo = o, ld = d, lidir = d;
     float scale = 1.0f, best_t = 0.0f;
@@ -295,7 +300,14 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
         if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) {
             st = ST_PRIM;
         } else {
-            cb += 128u;
+            // the next chunk whose union bound the ray meets (chunks past the 64th are not
+            // summarised in cmask and are all visited)
+            uint32_t next = (cb >> 7) + 1u;
+            if (MULTI && next < 64u) {
+                const unsigned long long rest = cmask >> next;
+                next = rest ? next + (uint32_t)__builtin_ctzll(rest) : 64u;
+            }
+            cb = next * 128u;
             if (cb < sc.n_prims) st = ST_SCAN;
             else retire();
         }
@@ -357,6 +369,7 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
             if (!drained) {
                 const uint32_t avail = run_end - run_next;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_m, 0u));
+                bool fresh = false;
                 if (st == ST_DONE && rank < avail) {
                     slot = run_next + rank;
                     const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
@@ -370,7 +383,9 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                         closest_prim = 0;
                         overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
                         cb = 0;
+                        if (MULTI) cmask = ~0ull;
                         st = ST_SCAN;
+                        fresh = true;
                         if (COUNT) c_rays++;
                         // A direction of NaNs (normalize() of a zero vector in the shading code)
                         // fails no box test and passes no triangle test: the reference walks
@@ -391,6 +406,26 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                     }
                 }
                 run_next += min(avail, n_done);
+                // scenes of more than one chunk: which chunks can the new rays touch at all
+                // (wave-uniform over the chunks' union bounds, scalar loads)
+                if (MULTI) {
+                    const f3 r = rcp3(d);
+                    const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
+                    const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+                    unsigned long long cm = 0ull;
+                    const uint32_t nc = min(sc.n_chunks, 64u);
+                    for (uint32_t ch = 0; ch < nc; ch++) {
+                        const rt_float8 u = *(rt_cfloat8_p)(sc.cbounds + (size_t)ch * 8u);
+                        const float b[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
+                        cm |= (overlaps_world_box(oi, idir, b) ? 1ull : 0ull) << ch;
+                    }
+                    if (nc < 64u) cm |= ~0ull << nc; // never 0: the chunks that do not exist end the walk
+                    if (fresh && st == ST_SCAN) {
+                        cmask = cm;
+                        cb = (uint32_t)__builtin_ctzll(cm) * 128u;
+                        if (cb >= sc.n_prims) retire();
+                    }
+                }
             }
             continue;
         }
@@ -406,7 +441,9 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
             const f3 r = rcp3(d);
             const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
             const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
-            // bounds come eight primitives at a time: six 32-byte scalar loads per group
+            // bounds come eight primitives at a time: six 32-byte scalar loads per group; in
+            // scenes of more than one chunk a group whose union bound no waiting lane meets is
+            // skipped as a whole
             uint32_t m[4];
             const uint32_t g0 = c0 >> 3;
 #pragma unroll
@@ -416,6 +453,11 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 for (uint32_t gg = 0; gg < 4u; gg++) {
                     const uint32_t g = g0 + 4u * w + gg;
                     if (g >= sc.n_prim_groups) break;
+                    if (MULTI) {
+                        const rt_float8 u = *(rt_cfloat8_p)(sc.gbounds + (size_t)g * 8u);
+                        const float ub[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
+                        if (__ballot(mine && overlaps_world_box(oi, idir, ub)) == 0ull) continue;
+                    }
                     const rt_cfloat8_p bp = (rt_cfloat8_p)(sc.wbounds + (size_t)g * 48u);
                     const rt_float8 lx = bp[0], ly = bp[1], lz = bp[2], hx = bp[3], hy = bp[4], hz = bp[5];
 #pragma unroll
@@ -432,12 +474,7 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
             if (mine) {
                 mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];
                 cb = c0;
-                if ((m[0] | m[1] | m[2] | m[3]) != 0u) {
-                    st = ST_PRIM;
-                } else {
-                    cb += 128u;
-                    if (cb >= sc.n_prims) retire();
-                }
+                advance(); // ST_PRIM if a bit is set, else on to the next chunk or done
             }
             continue;
         }

@@ -49,6 +49,8 @@ struct rthip_ctx {
     void*     d_exts = nullptr;
     void*     d_primx = nullptr;
     void*     d_wbounds = nullptr;
+    void*     d_gbounds = nullptr;
+    void*     d_cbounds = nullptr;
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
     void*     d_env = nullptr;
@@ -133,7 +135,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds);
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_cbounds);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -276,6 +278,24 @@ template <typename K> int occupancy_blocks(K kernel, int block) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 2;
     return nb;
 }
+
+// k_extend has three compile-time switches; these pick the instantiation for run-time flags.
+template <bool COUNT, bool DEEP> int extend_occupancy_t(bool multi) {
+    return multi ? occupancy_blocks(k_extend<COUNT, DEEP, true>, 256) : occupancy_blocks(k_extend<COUNT, DEEP, false>, 256);
+}
+int extend_occupancy(bool count, bool deep, bool multi) {
+    if (count) return deep ? extend_occupancy_t<true, true>(multi) : extend_occupancy_t<true, false>(multi);
+    return deep ? extend_occupancy_t<false, true>(multi) : extend_occupancy_t<false, false>(multi);
+}
+template <bool COUNT, bool DEEP> void extend_launch_t(bool multi, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
+    if (multi) hipLaunchKernelGGL((k_extend<COUNT, DEEP, true>), dim3(grid), dim3(256), 0, st, ea);
+    else hipLaunchKernelGGL((k_extend<COUNT, DEEP, false>), dim3(grid), dim3(256), 0, st, ea);
+}
+void extend_launch(bool count, bool deep, bool multi, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
+    if (count) { if (deep) extend_launch_t<true, true>(multi, grid, st, ea); else extend_launch_t<true, false>(multi, grid, st, ea); }
+    else { if (deep) extend_launch_t<false, true>(multi, grid, st, ea); else extend_launch_t<false, false>(multi, grid, st, ea); }
+}
+
 
 } // namespace
 
@@ -516,6 +536,25 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         for (int k = 0; k < 6; k++) grp[k * 8 + (p & 7u)] = wb[k];
     }
 
+    // union bounds per group of 8 and per chunk of 128 primitives
+    const uint32_t n_chunks = (s->n_prims + 127u) / 128u;
+    std::vector<float> gbounds((size_t)n_prim_groups * 8, 0.0f), cbounds((size_t)n_chunks * 8, 0.0f);
+    {
+        const float big = std::numeric_limits<float>::infinity();
+        for (uint32_t g = 0; g < n_prim_groups; g++) for (int k = 0; k < 3; k++) { gbounds[(size_t)g * 8 + k] = big; gbounds[(size_t)g * 8 + 3 + k] = -big; }
+        for (uint32_t ch = 0; ch < n_chunks; ch++) for (int k = 0; k < 3; k++) { cbounds[(size_t)ch * 8 + k] = big; cbounds[(size_t)ch * 8 + 3 + k] = -big; }
+        for (uint32_t p = 0; p < s->n_prims; p++) {
+            const float* grp = &wbounds[(size_t)(p >> 3) * 48];
+            float* gb = &gbounds[(size_t)(p >> 3) * 8];
+            float* cb = &cbounds[(size_t)(p >> 7) * 8];
+            for (int k = 0; k < 3; k++) {
+                const float lo = grp[k * 8 + (p & 7u)], hi = grp[(3 + k) * 8 + (p & 7u)];
+                gb[k] = std::min(gb[k], lo); gb[3 + k] = std::max(gb[3 + k], hi);
+                cb[k] = std::min(cb[k], lo); cb[3 + k] = std::max(cb[3 + k], hi);
+            }
+        }
+    }
+
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -529,6 +568,8 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     HIP_TRY(c, upload(c->d_tris, dev_tris.data(), sizeof(float) * dev_tris.size()));
     HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
     HIP_TRY(c, upload(c->d_wbounds, wbounds.data(), sizeof(float) * wbounds.size()));
+    HIP_TRY(c, upload(c->d_gbounds, gbounds.data(), sizeof(float) * gbounds.size()));
+    HIP_TRY(c, upload(c->d_cbounds, cbounds.data(), sizeof(float) * cbounds.size()));
     HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
     HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
     HIP_TRY(c, upload(c->d_texels, s->texels, sizeof(uint32_t) * s->n_texels));
@@ -540,6 +581,9 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->sc.primx = static_cast<const PrimX*>(c->d_primx);
     c->sc.wbounds = static_cast<const float*>(c->d_wbounds);
     c->sc.n_prim_groups = n_prim_groups;
+    c->sc.gbounds = static_cast<const float*>(c->d_gbounds);
+    c->sc.cbounds = static_cast<const float*>(c->d_cbounds);
+    c->sc.n_chunks = n_chunks;
     c->sc.prims = static_cast<const PrimitiveD*>(c->d_prims);
     c->sc.texels = static_cast<const uint32_t*>(c->d_texels);
     c->sc.env = static_cast<const float4*>(c->d_env);
@@ -658,9 +702,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
 
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const bool deep = P.stack_depth > RT_LDS_LEVELS;
-    int ext_blocks;
-    if (count) ext_blocks = deep ? occupancy_blocks(k_extend<true, true>, 256) : occupancy_blocks(k_extend<true, false>, 256);
-    else ext_blocks = deep ? occupancy_blocks(k_extend<false, true>, 256) : occupancy_blocks(k_extend<false, false>, 256);
+    const bool multi = c->sc.n_chunks > 1u;
+    int ext_blocks = extend_occupancy(count, deep, multi);
     if (const char* e = std::getenv("RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
         const int v = std::atoi(e);
         if (v > 0 && v <= 16) ext_blocks = v;
@@ -722,13 +765,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.nan_overflow = nanw.dropped ? 1u : 0u;
             {
                 StageTimer t(c, timing, RTHIP_STAGE_EXTEND);
-                if (count) {
-                    if (deep) hipLaunchKernelGGL((k_extend<true, true>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
-                    else hipLaunchKernelGGL((k_extend<true, false>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
-                } else {
-                    if (deep) hipLaunchKernelGGL((k_extend<false, true>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
-                    else hipLaunchKernelGGL((k_extend<false, false>), dim3(ext_grid), dim3(256), 0, c->stream, ea);
-                }
+                extend_launch(count, deep, multi, ext_grid, c->stream, ea);
             }
             ShadeArgs sa{};
             sa.sc = c->sc;
@@ -831,7 +868,8 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
     const bool deep = P.stack_depth > RT_LDS_LEVELS;
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
-    const int blocks = deep ? occupancy_blocks(k_extend<false, true>, 256) : occupancy_blocks(k_extend<false, false>, 256);
+    const bool multi = c->sc.n_chunks > 1u;
+    const int blocks = extend_occupancy(count, deep, multi);
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * blocks, (n + 255) / 256);
     if (deep) {
         const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_LDS_LEVELS) * grid * 256;
@@ -855,13 +893,7 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     ea.counters = c->d_counters;
     ea.nan_inner = nanw.inner; ea.nan_leaf = nanw.leaf; ea.nan_tri = nanw.tri; ea.nan_dropped = nanw.dropped;
     ea.nan_overflow = nanw.dropped ? 1u : 0u;
-    if (count) {
-        if (deep) hipLaunchKernelGGL((k_extend<true, true>), dim3(grid), dim3(256), 0, c->stream, ea);
-        else hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), 0, c->stream, ea);
-    } else {
-        if (deep) hipLaunchKernelGGL((k_extend<false, true>), dim3(grid), dim3(256), 0, c->stream, ea);
-        else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), 0, c->stream, ea);
-    }
+    extend_launch(count, deep, multi, grid, c->stream, ea);
     std::vector<float> hits((size_t)n * 4);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(hits.data(), d_hits, sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream);

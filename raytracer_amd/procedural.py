@@ -346,10 +346,12 @@ def terrain_mesh(n=60, size=40.0, seed=7):
     return grid(n, n, (size, size), height=height, uv_scale=8.0)
 
 
-def terrain_scene(tiles=1, n=60, env_size=(1024, 512)):
+def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False):
     """Stand-in for resources/simple_terrain.glb (a ~7 k-triangle plane plus a ~1 k-triangle
     object, own camera) and, with tiles > 1, for its tiling into one large primitive
-    (tiles^2 copies merged into one BVH): the HBM-resident traversal stress case."""
+    (tiles^2 copies merged into one BVH): the HBM-resident traversal stress case.  With
+    instanced=True the tiles stay 2 * tiles^2 primitives that share two BVHs: the stress case
+    for the number of primitives."""
     size = 40.0
     t = terrain_mesh(n, size)
     rock = uv_sphere(22, 23, radius=2.0)  # 968 triangles
@@ -358,6 +360,16 @@ def terrain_scene(tiles=1, n=60, env_size=(1024, 512)):
         s.add_primitive(t[0], t[1], normals=t[2], uv0=t[3], material=material(albedo=(0.8, 0.8, 0.8, 1), roughness=1.0))
         s.add_primitive(rock[0], rock[1], normals=rock[2], uv0=rock[3],
                         material=material(albedo=(0.8, 0.8, 0.8, 1), roughness=1.0), transform=host.trs((0.0, 0.0, 2.5)))
+    elif instanced:
+        mat = material(albedo=(0.8, 0.8, 0.8, 1), roughness=1.0)
+        pos = lambda i, j, z: host.trs(((i - tiles / 2 + 0.5) * size, (j - tiles / 2 + 0.5) * size, z))
+        pt = s.add_primitive(t[0], t[1], normals=t[2], uv0=t[3], material=mat, transform=pos(0, 0, 0.0))
+        pr = s.add_primitive(rock[0], rock[1], normals=rock[2], uv0=rock[3], material=mat, transform=pos(0, 0, 2.5))
+        for i in range(tiles):
+            for j in range(tiles):
+                if i or j:
+                    s.add_instance(pt, pos(i, j, 0.0))
+                    s.add_instance(pr, pos(i, j, 2.5))
     else:
         parts = []
         for i in range(tiles):

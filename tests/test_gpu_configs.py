@@ -184,3 +184,42 @@ def test_shallow_stack_on_deep_tree_overflows_like_the_oracle(ctx):
         for k in ("inner_steps", "tri_tests", "stack_overflows"):
             assert abs(got["counters"][k] - ref["counters"][k]) <= max(8, 2e-3 * ref["counters"][k]), (depth, k)
         assert (ref["counters"]["stack_overflows"] > 0) == (depth == 4)
+
+
+def test_many_primitives_span_several_chunks(ctx):
+    """288 instanced primitives (three chunks of 128 for the candidate scan, whose chunk and
+    group union bounds let whole chunks and groups be skipped): frames and single rays against
+    the oracle, which visits every primitive."""
+    s = procedural.terrain_scene(tiles=12, env_size=(128, 64), instanced=True)
+    a = s.arrays()
+    assert a["prims"].shape[0] == 288
+    res = (256, 144)
+    p = device.default_params(max_bounces=4)
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 2, 1, p)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    sc = oracle_scene(a)
+    ref = orc.render(sc, u, oracle_params(p), 1, 2, 1, taps=True, n_threads=THREADS)
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.9999
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.999
+    same = got["seed"] == ref["seed"]
+    assert np.array_equal(got["prim"][same & (got["tri"] >= 0)], ref["prim"][same & (ref["tri"] >= 0)])
+    np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
+    assert got["counters"]["prims_visited"] < 0.05 * ref["counters"]["root_tests"]
+    # single rays, bit for bit, from points above the terrain in all directions
+    rng = np.random.default_rng(3)
+    n = 400
+    o = np.column_stack([rng.uniform(-230, 230, n), rng.uniform(-230, 230, n), rng.uniform(0.5, 30, n)]).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q = ctx.trace_rays(o, d)
+    op = oracle_params(device.default_params())
+    for i in range(n):
+        tri, prim, t, _ = orc.trace_ray(sc, o[i], d[i], op, 0)
+        assert q["tri"][i] == tri, i
+        if tri >= 0:
+            assert q["prim"][i] == prim and q["t"][i] == np.float32(t), i
