@@ -192,6 +192,10 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 typedef float rt_float8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) rt_float8* rt_cfloat8_p;
 
+typedef float rt_float3 __attribute__((ext_vector_type(3)));
+// the first 12 bytes of a 16-byte row
+__device__ __forceinline__ rt_float3 ld12(const float4* row) { return *reinterpret_cast<const rt_float3*>(row); }
+
 // Address of a record given its position in 16-byte units (one 64-bit shift-add; the record's
 // further 16-byte pieces are immediate offsets of the loads).  32 bits of units span 64 GiB.
 __device__ __forceinline__ const float4* rec16(const void* base, uint32_t unit) {
@@ -521,10 +525,12 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
             if (COUNT) r_leaf += __ballot(two) ? 2u : 1u;
             if (st == ST_LEAF) {
                 const float4* tp = rec16(tris, cur_first * 3u);
-                const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                float4 b0 = a0, b1 = a1, b2 = a2;
-                if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
-                auto test = [&](float4 q0, float4 q1, float4 q2, uint32_t tri_i) {
+                // 12-byte loads: the fourth lane of a triangle's rows is padding, and the return path
+                // charges a wave-level load by its width
+                const rt_float3 a0 = ld12(tp), a1 = ld12(tp + 1), a2 = ld12(tp + 2);
+                rt_float3 b0 = a0, b1 = a1, b2 = a2;
+                if (two) { b0 = ld12(tp + 3); b1 = ld12(tp + 4); b2 = ld12(tp + 5); }
+                auto test = [&](rt_float3 q0, rt_float3 q1, rt_float3 q2, uint32_t tri_i) {
                     if (COUNT) c_tri++;
                     float u, v;
                     const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
@@ -571,7 +577,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
                 p = cb + k;
                 const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
-                const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], m3 = pp[3], r0 = pp[4], r1 = pp[5]; // r0, r1: the root node
+                const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[4], r1 = pp[5]; // r0, r1: the root node
+                const uint32_t settings = reinterpret_cast<const uint32_t*>(pp + 3)[1]; // alpha_settings
                 const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
                 // transform_ray + scale factor, shader.wgsl:604-607
                 const f3 td = xform_dir(d, inv);
@@ -579,8 +586,8 @@ __global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
                 ld = td / scale;
                 lo = xform_pos(o, inv);
                 lidir = rcp3(ld);
-                mode = __float_as_uint(m3.y) & 3u;
-                const bool nested = (__float_as_uint(m3.y) & RT_PRIMX_NESTED_ROOT) != 0u;
+                mode = settings & 3u;
+                const bool nested = (settings & RT_PRIMX_NESTED_ROOT) != 0u;
                 if (COUNT) c_prims++;
                 const float troot = hit_aabb_s(lo, lidir, r0, r1);
                 const uint32_t root_first = __float_as_uint(r1.z), root_count = __float_as_uint(r1.w);
