@@ -134,3 +134,35 @@ def test_single_ray_trace_box():
     assert tri >= 0 and prim == 0 and abs(t - 4.5) < 1e-5
     tri, prim, t, _ = orc.trace_ray(sc, (-5.0, 0.0, 2.0), (1.0, 0.0, 0.0))
     assert tri == -1 and prim == -1
+
+
+def test_builder_on_a_tree_derived_by_hand():
+    """Four unit triangles on the x axis at 0, 10, 20, 30 (scene.rs:888-1050 by hand): four
+    triangles are not a leaf (count > 2), fewer than 64 take the exact-centroid SAH, whose cost
+    2*A(11) + 2*A(11) for the split between the pairs beats 1*A(1) + 3*A(21) on either side by far,
+    so the root becomes inner with its children appended as nodes 1 and 2, each a leaf of two
+    triangles (count <= 2 stops the recursion); the partition (scene.rs:1004-1022) walks i up over
+    triangles 0 and 1, swaps triangle 2 with the last one and re-examines the swapped-in triangle 3,
+    which leaves the order 0, 1, 3, 2; every box is the min/max of its vertices widened by 0.00001
+    in f32."""
+    from raytracer_amd import layouts as L
+    xs = np.array([0.0, 10.0, 20.0, 30.0], np.float32)
+    tris = np.zeros(4, dtype=L.TRI)
+    for i, x in enumerate(xs):
+        p = np.array([[x, 0, 0], [x + 1, 0, 0], [x, 1, 0]], np.float32)
+        tris["v"][i, :, :3] = p
+        tris["v"][i, :, 3] = ((p[0] + p[1]) + p[2]) / np.float32(3.0)
+    nodes, idx = orc.bvh_build(tris, 0, 4)
+    assert nodes.shape == (3, 8)
+    assert np.array_equal(idx, [0, 1, 3, 2])
+    eps = np.float32(0.00001)
+
+    def box(a, b):
+        v = tris["v"][a:b, :, :3].reshape(-1, 3)
+        return np.concatenate([v.min(0) - eps, v.max(0) + eps]).astype(np.float32)
+
+    first_count = nodes.view(np.uint32)[:, 6:8]
+    assert first_count.tolist() == [[1, 0], [0, 2], [2, 2]]
+    assert np.array_equal(nodes[0, :6], box(0, 4))
+    assert np.array_equal(nodes[1, :6], box(0, 2))
+    assert np.array_equal(nodes[2, :6], box(2, 4))
