@@ -188,7 +188,15 @@ uint32_t frames_in_flight_limit(const rthip_ctx* c) {
         if (v >= 1 && v <= 64) want = (uint32_t)v;
     }
     const uint64_t slots = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
-    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * 160ull > (16ull << 30))) want--;
+    // 160 bytes of queues and results per path slot: at most 16 GiB, and at most half of what the
+    // device has free beyond what this context already holds for the purpose
+    uint64_t budget = 16ull << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const uint64_t held = c->queue_mem ? c->queue_cap * 160ull : 0ull;
+        budget = std::min<uint64_t>(budget, (free_b + held) / 2);
+    }
+    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * 160ull > budget)) want--;
     return want;
 }
 
