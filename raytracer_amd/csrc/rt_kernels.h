@@ -253,7 +253,7 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // tens of millions of triangles) continues in a global-memory column per thread, so that a deep
 // stack does not cost occupancy.  The reference does not re-test the box of a popped node either.
 template <bool COUNT, bool DEEP, bool MULTI>
-__global__ __launch_bounds__(256) void k_extend(ExtArgs a) {
+__global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
     const uint32_t lane = lane_id();
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (RT_LDS_LEVELS * RT_WAVE) + lane;
