@@ -44,7 +44,7 @@ def profiled_extend_traffic():
         text = open(PROFILE_SUMMARY).read()
     except OSError:
         return None
-    block = text.split("\n  void k_extend<false, false, false>(ExtArgs)\n")
+    block = text.split("\n  void k_extend<false, true, false>(ExtArgs)\n")
     if len(block) < 2:
         return None
     vals = {}

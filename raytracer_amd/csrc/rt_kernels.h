@@ -222,7 +222,19 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // dword when it fits (count < 16, first < 2^27), so that a pop needs no memory access; otherwise
 // bit 31 is set and the low bits are the node's index, whose record the pop re-reads.
 #define RT_STACK_RELOAD 0x80000000u
-#define RT_LDS_LEVELS 24u
+// the packed per-lane word (primitive, overflow flag, alpha mode): primitives are limited to 2^29
+#define RT_PM_PRIM 0x1FFFFFFFu
+#define RT_PM_OVERFLOW 0x20000000u
+#define RT_PM_MODE_SHIFT 30
+// Seven waves per SIMD: 28 waves of a CU share its 160 KB of LDS, which leaves 22 stack levels
+// per lane, and each wave gets 72 VGPRs.  (Measured: 6 waves with 24 levels 1.38 ms per frame of
+// the atrium, 7 with 22 1.34, 8 with 20 1.39.)
+#ifndef RT_LDS_LEVELS
+#define RT_LDS_LEVELS 22u
+#endif
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 7
+#endif
 #define RT_MAX_STACK 64u
 
 // trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
@@ -253,7 +265,7 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // tens of millions of triangles) continues in a global-memory column per thread, so that a deep
 // stack does not cost occupancy.  The reference does not re-test the box of a popped node either.
 template <bool COUNT, bool DEEP, bool MULTI>
-__global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
+__global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
     const uint32_t lane = lane_id();
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (RT_LDS_LEVELS * RT_WAVE) + lane;
@@ -273,29 +285,33 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
     bool drained = false;
 
     // per-lane
+    // per-lane.  What a ray needs only between primitives stays in memory, where it lives
+    // anyway, so that more waves fit a SIMD: origin and direction in the queue record, the closest
+    // hit so far and the seed in the hit record (written at fetch, updated by every primitive that
+    // gives a closer hit, complete when the ray retires).
     uint32_t st = ST_DONE;
-    uint32_t slot = 0, pix = RT_NO_PIXEL, seed = 0;
-    f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
-    int32_t closest_idx = -1;
-    float closest_t = 99999999.0f;
-    uint32_t closest_prim = 0;
-    bool overflow = false;
+    uint32_t slot = 0;
     uint32_t mask[4] = {0, 0, 0, 0};
-    uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes
+    uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes (MULTI)
     unsigned long long cmask = ~0ull; // bit c: the ray meets the union bound of chunk c (c < 64)
-    uint32_t p = 0, cur_first = 0, cur_count = 0, sp = 0, mode = 0;
-    f3 lo = o, ld = d, lidir = d;
+    uint32_t pm = 0; // RT_PM_PRIM: current primitive; RT_PM_OVERFLOW: a push of this ray was dropped; top bits: alpha mode
+    uint32_t cur_first = 0, cur_count = 0, sp = 0;
+    f3 lo = F3(0, 0, 0), ld = F3(0, 0, 1), lidir = ld;
     float scale = 1.0f, best_t = 0.0f;
     int32_t best_i = -1;
 
-    // the ray is finished: write its hit record, wait for a new ray
+    // the ray is finished: its hit record is complete but for the overflow flag
     auto retire = [&]() {
-        a.hits[slot] = make_float4(closest_t, __int_as_float(closest_idx),
-                                   __uint_as_float(closest_prim | (overflow ? 0x80000000u : 0u)), __uint_as_float(seed));
-        if (a.tap && pix < a.n_pixels) {
-            a.tap_tri[pix] = closest_idx;
-            a.tap_prim[pix] = closest_idx >= 0 ? (int32_t)closest_prim : -1;
-            a.tap_t[pix] = closest_t;
+        uint32_t* rec = reinterpret_cast<uint32_t*>(a.hits + slot);
+        if (pm & RT_PM_OVERFLOW) rec[2] |= 0x80000000u;
+        if (a.tap) {
+            const uint32_t pix = __float_as_uint(a.in.s1[slot].w);
+            if (pix < a.n_pixels) {
+                const int32_t idx = (int32_t)rec[1];
+                a.tap_tri[pix] = idx;
+                a.tap_prim[pix] = idx >= 0 ? (int32_t)(rec[2] & 0x7FFFFFFFu) : -1;
+                a.tap_t[pix] = __uint_as_float(rec[0]);
+            }
         }
         st = ST_DONE;
     };
@@ -306,22 +322,27 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
         } else {
             // the next chunk whose union bound the ray meets (chunks past the 64th are not
             // summarised in cmask and are all visited)
-            uint32_t next = (cb >> 7) + 1u;
-            if (MULTI && next < 64u) {
-                const unsigned long long rest = cmask >> next;
-                next = rest ? next + (uint32_t)__builtin_ctzll(rest) : 64u;
+            if (MULTI) {
+                uint32_t next = (cb >> 7) + 1u;
+                if (next < 64u) {
+                    const unsigned long long rest = cmask >> next;
+                    next = rest ? next + (uint32_t)__builtin_ctzll(rest) : 64u;
+                }
+                cb = next * 128u;
+                if (cb < sc.n_prims) st = ST_SCAN;
+                else retire();
+            } else {
+                retire(); // at most 128 primitives: one chunk
             }
-            cb = next * 128u;
-            if (cb < sc.n_prims) st = ST_SCAN;
-            else retire();
         }
     };
     // the traversal of primitive p ended: shader.wgsl:610-614
     auto finish = [&]() {
         if (best_i >= 0) {
-            closest_t = best_t / scale;
-            closest_idx = best_i;
-            closest_prim = p;
+            float* rec = reinterpret_cast<float*>(a.hits + slot);
+            rec[0] = best_t / scale;
+            rec[1] = __int_as_float(best_i);
+            rec[2] = __uint_as_float(pm & RT_PM_PRIM);
         }
         advance();
     };
@@ -374,18 +395,16 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                 const uint32_t avail = run_end - run_next;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_m, 0u));
                 bool fresh = false;
+                f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
                 if (st == ST_DONE && rank < avail) {
                     slot = run_next + rank;
                     const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
-                    pix = __float_as_uint(s1.w);
-                    if (pix != RT_NO_PIXEL) { // slots outside the image carry no ray
+                    if (__float_as_uint(s1.w) != RT_NO_PIXEL) { // slots outside the image carry no ray
                         o = F3(s0.x, s0.y, s0.z);
                         d = F3(s0.w, s1.x, s1.y);
-                        seed = __float_as_uint(s1.z);
-                        closest_idx = -1;
-                        closest_t = 99999999.0f;
-                        closest_prim = 0;
-                        overflow = false; // `debug` is reset by every trace(), shader.wgsl:602
+                        // no hit yet; `debug` (here: the overflow flag) is reset by every trace(), shader.wgsl:602
+                        a.hits[slot] = make_float4(99999999.0f, __int_as_float(-1), 0.0f, s1.z);
+                        pm = 0;
                         cb = 0;
                         if (MULTI) cmask = ~0ull;
                         st = ST_SCAN;
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                         // hold its wave for the whole tree walk, so its outcome (the miss, the
                         // dropped pushes, the step counts) is precomputed by the host.
                         if (d.x != d.x && d.y != d.y && d.z != d.z) {
-                            overflow = a.nan_overflow != 0u;
+                            if (a.nan_overflow != 0u) pm = RT_PM_OVERFLOW;
                             if (COUNT) {
                                 c_prims += sc.n_prims;
                                 c_inner += a.nan_inner;
@@ -437,8 +456,14 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
         // ---- candidate scan for the lanes that wait for a mask (wave-uniform over primitives)
         if (n_scan != 0u && (n_scan >= RT_SCAN_LANES || n_trav == 0u)) {
             // the chunk the first waiting lane wants; lanes that want another chunk wait for a later scan
-            const uint32_t c0 = __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(scan_m));
-            const bool mine = st == ST_SCAN && cb == c0;
+            const uint32_t c0 = MULTI ? __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(scan_m)) : 0u;
+            const bool mine = st == ST_SCAN && (!MULTI || cb == c0);
+            f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+            if (mine) {
+                const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+                o = F3(s0.x, s0.y, s0.z);
+                d = F3(s0.w, s1.x, s1.y);
+            }
             // A zero direction component makes 1/d infinite and b * inf - o * inf a NaN that would
             // silently drop that axis' bound on one side only; a huge finite reciprocal keeps the
             // sign logic of the slab test intact (the reference's own tests keep the true 1/d).
@@ -477,7 +502,6 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
             }
             if (mine) {
                 mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];
-                cb = c0;
                 advance(); // ST_PRIM if a bit is set, else on to the next chunk or done
             }
             continue;
@@ -510,7 +534,7 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                                 else stack[sp * RT_WAVE] = e;
                                 sp++;
                             }
-                            else { overflow = true; if (COUNT) c_over++; } // shader.wgsl:306-313
+                            else { pm |= RT_PM_OVERFLOW; if (COUNT) c_over++; } // shader.wgsl:306-313
                         }
                         enter(__float_as_uint(go_left ? l1.z : q1.z), __float_as_uint(go_left ? l1.w : q1.w));
                     }
@@ -536,9 +560,10 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                     const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
                     if (t >= 0.0f && t < best_t) {
                         bool accept = true;
-                        if (mode != 0u) { // shader.wgsl:464-487
+                        if (pm >= (1u << RT_PM_MODE_SHIFT)) { // shader.wgsl:464-487
                             if (COUNT) c_alpha++;
-                            const PrimX& px = sc.primx[p];
+                            const uint32_t mode = pm >> RT_PM_MODE_SHIFT;
+                            const PrimX& px = sc.primx[pm & RT_PM_PRIM];
                             const float w0 = (1.0f - u) - v;
                             const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
                             const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)tri_i);
@@ -554,7 +579,12 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                                 alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
                             }
                             if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
-                            else accept = !(rnd(seed) > alpha);
+                            else { // BLEND draws from the path's random stream: the seed lives in the hit record
+                                uint32_t* sw = reinterpret_cast<uint32_t*>(a.hits + slot) + 3;
+                                uint32_t seed = *sw;
+                                accept = !(rnd(seed) > alpha);
+                                *sw = seed;
+                            }
                         }
                         if (accept) { best_i = (int32_t)tri_i; best_t = t; }
                     }
@@ -575,7 +605,10 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                 else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
                 else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
                 else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
-                p = cb + k;
+                const uint32_t p = (MULTI ? cb : 0u) + k;
+                const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+                const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
+                const float closest_t = a.hits[slot].x;
                 const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
                 const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[4], r1 = pp[5]; // r0, r1: the root node
                 const uint32_t settings = reinterpret_cast<const uint32_t*>(pp + 3)[1]; // alpha_settings
@@ -586,7 +619,7 @@ __global__ __launch_bounds__(256, 6) void k_extend(ExtArgs a) {
                 ld = td / scale;
                 lo = xform_pos(o, inv);
                 lidir = rcp3(ld);
-                mode = settings & 3u;
+                pm = (pm & RT_PM_OVERFLOW) | p | ((settings & 3u) << RT_PM_MODE_SHIFT);
                 const bool nested = (settings & RT_PRIMX_NESTED_ROOT) != 0u;
                 if (COUNT) c_prims++;
                 const float troot = hit_aabb_s(lo, lidir, r0, r1);

@@ -410,6 +410,9 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (s->n_tris * 3ull >= 0xFFFFFFFFull || s->n_prims * 7ull >= 0xFFFFFFFFull)
         return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: triangle or primitive array of 64 GiB or more (%llu triangles, %u primitives)",
                     (unsigned long long)s->n_tris, s->n_prims);
+    // the extend stage keeps the primitive index in 29 bits of a packed word
+    if (s->n_prims > RT_PM_PRIM)
+        return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: more than 2^29-1 primitives (%u)", s->n_prims);
 
     const HostNode*   nodes = static_cast<const HostNode*>(s->nodes);
     const HostTri*    tris = static_cast<const HostTri*>(s->tris);
