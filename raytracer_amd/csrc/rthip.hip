@@ -662,6 +662,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     std::memcpy(&prim_count, c->uniforms + 600, 4);
     if (prim_count != c->sc.n_prims) return fail(c, RTHIP_ERR_INVALID, "render: uniforms say %u primitives, scene has %u", prim_count, c->sc.n_prims);
     if (n_frames == 0) return RTHIP_OK;
+    (void)hipGetLastError(); // an error left behind by other code of the process is not this call's
 
     DeviceGuard g(c->device);
     const uint32_t group = std::min<uint32_t>(n_frames, frames_in_flight_limit(c));
@@ -904,6 +905,7 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     ea.counters = c->d_counters;
     ea.nan_inner = nanw.inner; ea.nan_leaf = nanw.leaf; ea.nan_tri = nanw.tri; ea.nan_dropped = nanw.dropped;
     ea.nan_overflow = nanw.dropped ? 1u : 0u;
+    (void)hipGetLastError(); // not this call's
     extend_launch(count, deep, multi, grid, c->stream, ea);
     std::vector<float> hits((size_t)n * 4);
     e = hipGetLastError();

@@ -96,6 +96,28 @@ extern "C" {
     pub fn rthip_synchronize(ctx: *mut rthip_ctx) -> c_int;
 }
 
+/// `include/rthip_group.h` (librthip_group.so): all GPUs of a node from this one process.
+#[repr(C)]
+pub struct rthip_group {
+    _private: [u8; 0],
+}
+
+#[link(name = "rthip_group")]
+extern "C" {
+    pub fn rthip_group_create(device_ordinals: *const c_int, n_devices: c_int, out: *mut *mut rthip_group) -> c_int;
+    pub fn rthip_group_destroy(g: *mut rthip_group);
+    pub fn rthip_group_last_error(g: *const rthip_group) -> *const c_char;
+    pub fn rthip_group_size(g: *const rthip_group) -> c_int;
+    pub fn rthip_group_ctx(g: *mut rthip_group, rank: c_int) -> *mut rthip_ctx;
+    pub fn rthip_group_upload_scene(g: *mut rthip_group, scene: *const rthip_scene_desc) -> c_int;
+    pub fn rthip_group_set_frame_uniforms(g: *mut rthip_group, blob608: *const c_void) -> c_int;
+    pub fn rthip_group_plan(first_frame: u32, n_frames: u32, n_ranks: c_int, rank: c_int, first: *mut u32, count: *mut u32);
+    pub fn rthip_group_render(g: *mut rthip_group, first_frame: u32, n_frames: u32, params: *const rthip_render_params) -> c_int;
+    pub fn rthip_group_reduce(g: *mut rthip_group, root: c_int) -> c_int;
+    pub fn rthip_group_synchronize(g: *mut rthip_group) -> c_int;
+}
+
+
 #[derive(Debug)]
 pub struct Error {
     pub code: i32,

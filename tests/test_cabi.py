@@ -6,7 +6,7 @@ import re
 
 import pytest
 
-from raytracer_amd import device, host
+from raytracer_amd import device, group, host
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,6 +24,25 @@ def test_rthip_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(device.EXPORTS) == names
+
+
+def test_rthip_group_exports_every_declared_symbol():
+    names = declared("rthip_group.h", "rthip_group")
+    lib = group.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(group.EXPORTS) == names
+
+
+def test_group_plan_stripes_every_frame_exactly_once():
+    """GPU r of n renders frames first + r, first + r + n, ...: together all of them, once."""
+    for first, total, n in ((1, 64, 8), (1, 5, 8), (7, 1024, 3), (1, 0, 4), (100, 33, 1)):
+        seen = []
+        for r in range(n):
+            f, c = group.plan(first, total, n, r)
+            assert f == first + r
+            seen += [f + k * n for k in range(c)]
+        assert sorted(seen) == list(range(first, first + total)), (first, total, n)
 
 
 def test_rthost_exports_every_declared_symbol():
