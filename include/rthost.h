@@ -100,7 +100,7 @@ int rthost_scene_load_gltf_file(rthost_scene* s, const char* path);
 int rthost_scene_load_hdr_file(rthost_scene* s, const char* path);
 
 /* .rtscene cache: every flat array of the scene (and its cameras) in one file, written once and
- * then only read.  For scenes whose source needs a decoder this build lacks (JPEG textures) or
+ * then only read.  For scenes whose source needs a decoder this build lacks (CMYK JPEG, ...) or
  * that take long to build; the reference's Rust host can write the same file because its Vecs
  * hold the same bytes (scene.rs:239-251).  load_cache replaces the scene's content and refuses
  * files whose lengths or tree indices are inconsistent.  Layout: csrc/host/cache.cpp. */

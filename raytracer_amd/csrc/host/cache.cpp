@@ -1,5 +1,5 @@
 // .rtscene: the flat arrays of a loaded scene in one file, so that a scene whose source needs a
-// decoder this build does not have (JPEG textures), or that takes long to build, is prepared
+// decoder this build does not have (CMYK JPEG, ...), or that takes long to build, is prepared
 // once -- by this library or by the reference's Rust host, whose Vecs have the same bytes
 // (scene.rs:239-251) -- and then only read.
 //

@@ -313,9 +313,10 @@ struct Loader {
         if (rc != RTHOST_OK) return rc;
         uint32_t w = 0, h = 0;
         std::string e;
-        if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8)
-            return fail_doc(d, "JPEG textures need a decoder this build does not have; convert them to PNG");
-        if (!decode_png(bytes.data(), bytes.size(), rgba, w, h, e)) return fail_doc(d, "image decode: " + e);
+        // image::load_from_memory guesses the format from the content (scene.rs:310, 318)
+        const bool is_jpeg = bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8;
+        if (!(is_jpeg ? decode_jpeg(bytes.data(), bytes.size(), rgba, w, h, e) : decode_png(bytes.data(), bytes.size(), rgba, w, h, e)))
+            return fail_doc(d, "image decode: " + e);
         rc = rthost::add_texture(s, rgba.data(), w, h, &out);
         if (rc != RTHOST_OK) return rc;
         texture_map[tex_idx] = out;

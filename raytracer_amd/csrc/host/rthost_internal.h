@@ -71,10 +71,12 @@ void mat4_inverse_f32(const float m[16], float out[16]);
 void pack_oct(const float n[3], float out[2]);
 uint32_t pack_alpha(uint32_t mode, float cutoff);
 
-// gltf.cpp / png.cpp / hdr.cpp
+// gltf.cpp / png.cpp / jpeg.cpp / hdr.cpp
 int load_gltf(Scene& s, const uint8_t* bytes, size_t n, const std::string& base_dir);
 bool decode_png(const uint8_t* bytes, size_t n, std::vector<uint8_t>& rgba8, uint32_t& w,
                 uint32_t& h, std::string& err);
+bool decode_jpeg(const uint8_t* bytes, size_t n, std::vector<uint8_t>& rgba8, uint32_t& w,
+                 uint32_t& h, std::string& err);
 bool decode_hdr(const uint8_t* bytes, size_t n, std::vector<float>& rgba32f, uint32_t& w,
                 uint32_t& h, std::string& err);
 bool read_file(const std::string& path, std::vector<uint8_t>& out);

@@ -154,17 +154,64 @@ def test_png_decoder_matches_pil(mode):
     assert np.array_equal(got, want)
 
 
-def test_jpeg_is_reported_as_unsupported():
+def _texture_through_gltf(image_bytes, mime, w, h):
     g = Glb()
     pos, nrm, uv, idx = quad()
-    buf = io.BytesIO()
-    Image.new("RGB", (4, 4)).save(buf, "JPEG")
-    g.doc["images"].append({"bufferView": g._view(buf.getvalue()), "mimeType": "image/jpeg"})
+    g.doc["images"].append({"bufferView": g._view(image_bytes), "mimeType": mime})
     g.doc["textures"].append({"source": 0})
     mat = g.material(pbrMetallicRoughness={"baseColorTexture": {"index": 0}})
-    g.node(mesh=g.mesh([{"attributes": {"POSITION": g.accessor(pos, "VEC3", 5126)}, "indices": g.accessor(idx, "SCALAR", 5123), "material": mat}]))
+    g.node(mesh=g.mesh([{"attributes": {"POSITION": g.accessor(pos, "VEC3", 5126), "TEXCOORD_0": g.accessor(uv, "VEC2", 5126)},
+                         "indices": g.accessor(idx, "SCALAR", 5123), "material": mat}]))
+    s = host.Scene()
+    s.add_gltf_bytes(g.tobytes())
+    t = s.texture_data
+    return np.stack([(t >> 24) & 255, (t >> 16) & 255, (t >> 8) & 255, t & 255], -1).reshape(h, w, 4)
+
+
+def _photo(w, h, seed=5):
+    """Smooth colour gradients plus noise and a hard edge: exercises every DCT coefficient."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 5.0), 128 + 110 * np.cos((x + y) / 9.0),
+                    255.0 * ((x // 6 + y // 4) % 2)], -1) + rng.normal(0, 12, (h, w, 3))
+    return Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), "RGB")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(subsampling=0), dict(subsampling=1), dict(subsampling=2),
+    dict(subsampling=2, progressive=True), dict(subsampling=0, progressive=True, quality=95),
+    dict(subsampling=2, quality=30, optimize=True), dict(gray=True), dict(gray=True, progressive=True),
+    dict(subsampling=1, restart_marker_blocks=3), dict(subsampling=2, size=(1, 1)), dict(subsampling=2, size=(3, 2)),
+    dict(subsampling=2, size=(16, 8)), dict(subsampling=1, size=(250, 3)), dict(subsampling="4:1:1"),
+])
+def test_jpeg_decoder_matches_libjpeg(kw):
+    """Baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0, grayscale, restart intervals, odd sizes: the
+    texels equal those of the libjpeg family (PIL), whose arithmetic the decoder follows."""
+    kw = dict(kw)
+    w, h = kw.pop("size", (61, 45))
+    img = _photo(w, h)
+    if kw.pop("gray", False):
+        img = img.convert("L")
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", **{"quality": 85, **kw})
+    want = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA")).astype(np.int32)
+    got = _texture_through_gltf(buf.getvalue(), "image/jpeg", w, h).astype(np.int32)
+    assert got.shape == want.shape and np.all(got[..., 3] == 255)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+def test_jpeg_errors_are_reported():
+    buf = io.BytesIO()
+    _photo(32, 32).save(buf, "JPEG")
+    data = buf.getvalue()
     with pytest.raises(host.RtHostError, match="JPEG"):
-        host.Scene().add_gltf_bytes(g.tobytes())
+        _texture_through_gltf(data[:2] + b"\xff\xc9\x00\x04\x00\x00" + data[2:], "image/jpeg", 32, 32)  # arithmetic coding
+    with pytest.raises(host.RtHostError, match="JPEG"):
+        _texture_through_gltf(data[:20], "image/jpeg", 32, 32)
+    cmyk = io.BytesIO()
+    _photo(16, 16).convert("CMYK").save(cmyk, "JPEG")
+    with pytest.raises(host.RtHostError, match="three-component"):
+        _texture_through_gltf(cmyk.getvalue(), "image/jpeg", 16, 16)
 
 
 def rgbe_encode(rgb):

@@ -4,8 +4,8 @@
     python tools/bake_scene.py scene.glb [env.hdr] -o scene.rtscene
 
 The file holds the flat arrays the device library uploads (layout: csrc/host/cache.cpp) and is
-what `bench.py --scene` and `Scene.from_cache` read.  Scenes with JPEG textures cannot be decoded
-by this build; bake those with the reference's Rust host (INTEGRATION.md shows the writer).
+what `bench.py --scene` and `Scene.from_cache` read.  PNG and JPEG textures are decoded here; the
+reference's Rust host can write the same file (INTEGRATION.md shows the writer).
 """
 import argparse
 import os
