@@ -241,7 +241,7 @@ def main():
                 "parallelism": f"spp-split x{n_gpus}" if n_gpus > 1 else "single",
             },
             "rays_per_step_per_gpu": round(rays_local / K, 1),
-            "stage_ms_per_step": {s: round(timing[s]["ms"] / K, 4) for s in ("generate", "extend", "shade", "accumulate")},
+            "stage_ms_per_step": {s: round(timing[s]["ms"] / K, 4) for s in ("generate", "cull", "extend", "shade", "accumulate")},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_extend",

@@ -97,7 +97,8 @@ typedef struct {
 #define RTHIP_STAGE_RESOLVE  3
 #define RTHIP_STAGE_ACCUMULATE 4 /* frame-ordered sum of the per-frame results into screen  */
 #define RTHIP_STAGE_SHADOW   5   /* enable_sun only: the shadow rays of a bounce             */
-#define RTHIP_NUM_STAGES     6
+#define RTHIP_STAGE_CULL     6   /* candidate primitives per ray (scenes of up to 128 primitives) */
+#define RTHIP_NUM_STAGES     7
 
 typedef struct {
     double   ms[RTHIP_NUM_STAGES];        /* summed kernel time per stage, HIP events       */

@@ -1,5 +1,6 @@
 // The stages of the path-tracing hot path as HIP kernels for gfx950 (wave64):
 //   generate    camera rays of a group of frames  (shader.wgsl:895-897, 741-779)
+//   cull        candidate primitives of each ray  (shader.wgsl:603-615; scenes of up to 128 primitives)
 //   extend      closest-hit traversal             (shader.wgsl:598-627, 442-525, 339-438)
 //   shade       miss / kill / BRDF                (shader.wgsl:898-914, 803-885, 941-946)
 //   accumulate  frame-ordered sum into screen     (shader.wgsl:947-951)
@@ -218,6 +219,76 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
     return inside ? 0.0f : r;
 }
 
+// The clamped reciprocal direction and origin * reciprocal the world-bound test works with.  A
+// zero direction component makes 1/d infinite and b * inf - o * inf a NaN that would silently
+// drop that axis' bound on one side only; a huge finite reciprocal keeps the sign logic of the
+// slab test intact (the reference's own tests keep the true 1/d).
+__device__ __forceinline__ void world_test_ray(f3 o, f3 d, f3& oi, f3& idir) {
+    const f3 r = rcp3(d);
+    idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
+    oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+}
+
+// ------------------------------------------------------------------ cull
+
+struct CullArgs {
+    SceneDev  sc;
+    PathQueue in;
+    uint4*    masks;          // per queue slot: bit p set = the ray meets the padded world bound of primitive p
+    const uint32_t* count_in;
+};
+
+// Candidate primitives of every ray of a queue, for scenes of at most 128 primitives: the
+// per-primitive loop of trace() (shader.wgsl:603-615) visits only primitives whose padded
+// world-space bound the ray meets, and skipping the others changes nothing the reference would
+// compute.  One lane per ray, all lanes busy, bounds through the scalar cache eight primitives
+// at a time: the same test inside the extend stage ran for the few lanes that had just fetched a
+// ray and cost a fifth of that stage.
+__global__ __launch_bounds__(256) void k_cull(CullArgs a) {
+    const uint32_t n = *a.count_in;
+    const SceneDev& sc = a.sc;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t slot = base + threadIdx.x;
+        f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+        bool live = false;
+        if (slot < n) {
+            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+            live = __float_as_uint(s1.w) != RT_NO_PIXEL;
+            o = F3(s0.x, s0.y, s0.z);
+            d = F3(s0.w, s1.x, s1.y);
+        }
+        f3 oi, idir;
+        world_test_ray(o, d, oi, idir);
+        uint32_t m[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t mw = 0;
+#pragma unroll 1
+            for (uint32_t gg = 0; gg < 4u; gg++) {
+                const uint32_t g = 4u * w + gg;
+                if (g >= sc.n_prim_groups) break;
+                // a group whose union bound none of the wave's rays meets is skipped as a whole
+                // (neighbouring queue slots hold neighbouring rays)
+                const rt_float8 u = *(rt_cfloat8_p)(sc.gbounds + (size_t)g * 8u);
+                const float ub[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
+                if (__ballot(live && overlaps_world_box(oi, idir, ub)) == 0ull) continue;
+                const rt_cfloat8_p bp = (rt_cfloat8_p)(sc.wbounds + (size_t)g * 48u);
+                const rt_float8 lx = bp[0], ly = bp[1], lz = bp[2], hx = bp[3], hy = bp[4], hz = bp[5];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float b[6] = {lx[k], ly[k], lz[k], hx[k], hy[k], hz[k]};
+                    mw |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (gg * 8u + k);
+                }
+            }
+            // the last group is padded to eight: drop the bits of primitives that do not exist
+            const uint32_t first = 32u * w;
+            const uint32_t have = sc.n_prims > first ? min(sc.n_prims - first, 32u) : 0u;
+            m[w] = have >= 32u ? mw : (mw & ((1u << have) - 1u));
+        }
+        if (live) a.masks[slot] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
+}
+
 // A traversal stack entry is the (first, count) pair of the postponed node packed into one
 // dword when it fits (count < 16, first < 2^27), so that a pop needs no memory access; otherwise
 // bit 31 is set and the low bits are the node's index, whose record the pop re-reads.
@@ -226,14 +297,15 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 #define RT_PM_PRIM 0x1FFFFFFFu
 #define RT_PM_OVERFLOW 0x20000000u
 #define RT_PM_MODE_SHIFT 30
-// Seven waves per SIMD: 28 waves of a CU share its 160 KB of LDS, which leaves 22 stack levels
-// per lane, and each wave gets 72 VGPRs.  (Measured: 6 waves with 24 levels 1.38 ms per frame of
-// the atrium, 7 with 22 1.34, 8 with 20 1.39.)
+// Eight waves per SIMD: 32 waves of a CU share its 160 KB of LDS, which leaves 19 stack levels
+// per lane, and each wave gets 64 VGPRs.  (Measured per frame of the atrium, with the candidate
+// scan still inside this kernel: 6 waves with 24 levels 1.38 ms, 7 with 22 1.34, 8 with 20 1.39;
+// with the scan in its own kernel the lane state fits 64 registers: 7 waves 1.12 ms, 8 waves 1.10.)
 #ifndef RT_LDS_LEVELS
-#define RT_LDS_LEVELS 22u
+#define RT_LDS_LEVELS 19u
 #endif
 #ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 7
+#define RT_EXTEND_WAVES 8
 #endif
 #define RT_MAX_STACK 64u
 
@@ -252,13 +324,15 @@ __device__ __forceinline__ float hit_aabb_s(f3 o, f3 idir, float4 q0, float4 q1)
 // are waiting, the waiting lanes take the next reserved slots.  No lane idles until the
 // slowest ray of a batch is done.
 //
-// MULTI instantiation (scenes of more than 128 primitives): every chunk of 128 and every group
-// of eight primitives also has a union bound; a new ray first learns which chunks it can touch
-// at all (cmask), and the scan of a chunk skips the groups that no waiting lane's ray meets.
+// Candidate primitives: a per-lane bit mask of the primitives whose padded world-space bound
+// the ray meets; skipping the others changes nothing the reference would compute.  For scenes of
+// up to 128 primitives the mask was computed by k_cull and waits in the ray's hit record.
 //
-// Candidate primitives come from a wave-uniform scan of padded world-space bounds (scalar
-// loads of eight primitives' bounds at a time), 128 primitives per chunk, recorded as a per-lane bit mask; skipping a primitive whose
-// bound the ray misses changes nothing the reference would compute.
+// MULTI instantiation (scenes of more than 128 primitives): the mask describes one chunk of 128
+// primitives at a time and comes from a wave-uniform scan inside this kernel (scalar loads of
+// eight primitives' bounds at a time) for the lanes that wait for one.  Every chunk and every
+// group of eight primitives also has a union bound; a new ray first learns which chunks it can
+// touch at all (cmask), and the scan of a chunk skips the groups that no waiting lane's ray meets.
 //
 // The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free) for
 // the first RT_LDS_LEVELS entries; the DEEP instantiation (stack_depth above that, for trees of
@@ -270,8 +344,11 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
     const uint32_t lane = lane_id();
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (RT_LDS_LEVELS * RT_WAVE) + lane;
     // levels RT_LDS_LEVELS.. of a deep stack: one global dword column per thread of the grid
-    uint32_t* spill = DEEP ? a.spill + (blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
+    // (addressed from the thread index at each use: a pointer per lane would cost two registers)
     const size_t spill_stride = (size_t)gridDim.x * blockDim.x;
+    auto spill_at = [&](uint32_t level) -> uint32_t& {
+        return a.spill[(size_t)(level - RT_LDS_LEVELS) * spill_stride + (blockIdx.x * blockDim.x + threadIdx.x)];
+    };
     const uint32_t n = *a.count_in;
     const uint32_t depth = DEEP ? min(a.stack_depth, RT_MAX_STACK) : min(a.stack_depth, RT_LDS_LEVELS);
     const SceneDev& sc = a.sc;
@@ -357,7 +434,7 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
             finish();
         } else {
             --sp;
-            const uint32_t e = (DEEP && sp >= RT_LDS_LEVELS) ? spill[(sp - RT_LDS_LEVELS) * spill_stride] : stack[sp * RT_WAVE];
+            const uint32_t e = (DEEP && sp >= RT_LDS_LEVELS) ? spill_at(sp) : stack[sp * RT_WAVE];
             uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
             if (e & RT_STACK_RELOAD) {
                 const float4 q = rec16(nodes, (e & 0x7FFFFFFFu) * 2u)[1];
@@ -402,6 +479,10 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
                     if (__float_as_uint(s1.w) != RT_NO_PIXEL) { // slots outside the image carry no ray
                         o = F3(s0.x, s0.y, s0.z);
                         d = F3(s0.w, s1.x, s1.y);
+                        if (!MULTI) { // the candidate mask the cull stage left in the ray's hit record
+                            const uint4 mk = *reinterpret_cast<const uint4*>(a.hits + slot);
+                            mask[0] = mk.x; mask[1] = mk.y; mask[2] = mk.z; mask[3] = mk.w;
+                        }
                         // no hit yet; `debug` (here: the overflow flag) is reset by every trace(), shader.wgsl:602
                         a.hits[slot] = make_float4(99999999.0f, __int_as_float(-1), 0.0f, s1.z);
                         pm = 0;
@@ -425,6 +506,8 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
                                 c_over += a.nan_dropped;
                             }
                             retire();
+                        } else if (!MULTI) {
+                            advance(); // first candidate, or done if the ray meets no primitive's bound
                         }
                     }
                 }
@@ -454,7 +537,7 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
         }
 
         // ---- candidate scan for the lanes that wait for a mask (wave-uniform over primitives)
-        if (n_scan != 0u && (n_scan >= RT_SCAN_LANES || n_trav == 0u)) {
+        if (MULTI && n_scan != 0u && (n_scan >= RT_SCAN_LANES || n_trav == 0u)) {
             // the chunk the first waiting lane wants; lanes that want another chunk wait for a later scan
             const uint32_t c0 = MULTI ? __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(scan_m)) : 0u;
             const bool mine = st == ST_SCAN && (!MULTI || cb == c0);
@@ -530,7 +613,7 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
                                 const uint32_t ff = __float_as_uint(go_left ? q1.z : l1.z), fc = __float_as_uint(go_left ? q1.w : l1.w);
                                 const uint32_t nd = go_left ? cur_first + 1u : cur_first;
                                 const uint32_t e = (fc < 16u && ff < 0x08000000u) ? (ff | (fc << 27)) : (RT_STACK_RELOAD | nd);
-                                if (DEEP && sp >= RT_LDS_LEVELS) spill[(sp - RT_LDS_LEVELS) * spill_stride] = e;
+                                if (DEEP && sp >= RT_LDS_LEVELS) spill_at(sp) = e;
                                 else stack[sp * RT_WAVE] = e;
                                 sp++;
                             }

@@ -775,6 +775,15 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.nan_tri = nanw.tri;
             ea.nan_dropped = nanw.dropped;
             ea.nan_overflow = nanw.dropped ? 1u : 0u;
+            if (!multi) {
+                CullArgs ca{};
+                ca.sc = c->sc;
+                ca.in = q[b & 1];
+                ca.masks = reinterpret_cast<uint4*>(c->hits);
+                ca.count_in = c->ctrl + b;
+                StageTimer t(c, timing, RTHIP_STAGE_CULL);
+                hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
+            }
             {
                 StageTimer t(c, timing, RTHIP_STAGE_EXTEND);
                 extend_launch(count, deep, multi, ext_grid, c->stream, ea);
@@ -906,6 +915,14 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     ea.nan_inner = nanw.inner; ea.nan_leaf = nanw.leaf; ea.nan_tri = nanw.tri; ea.nan_dropped = nanw.dropped;
     ea.nan_overflow = nanw.dropped ? 1u : 0u;
     (void)hipGetLastError(); // not this call's
+    if (!multi) {
+        CullArgs ca{};
+        ca.sc = c->sc;
+        ca.in = ea.in;
+        ca.masks = reinterpret_cast<uint4*>(d_hits);
+        ca.count_in = d_ctl;
+        hipLaunchKernelGGL(k_cull, dim3((uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n + 255) / 256)), dim3(256), 0, c->stream, ca);
+    }
     extend_launch(count, deep, multi, grid, c->stream, ea);
     std::vector<float> hits((size_t)n * 4);
     e = hipGetLastError();

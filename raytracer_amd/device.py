@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
 FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
-STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "shadow")
+STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "shadow", "cull")
 
 EXPORTS = (
     "rthip_device_count", "rthip_create", "rthip_destroy", "rthip_last_error", "rthip_set_stream",
