@@ -140,7 +140,7 @@ struct ExtArgs {
     uint32_t  stack_depth;
     uint32_t  tap;            // 1: record primary hits per pixel (paths of frame slot 0 only)
     uint32_t  n_pixels;
-    uint32_t  pad;
+    uint32_t  no_cull;        // 1: no candidate masks were computed (a handful of primitives): every primitive is a candidate
     int32_t*  tap_tri;
     int32_t*  tap_prim;
     float*    tap_t;
@@ -231,6 +231,9 @@ __device__ __forceinline__ void world_test_ray(f3 o, f3 d, f3& oi, f3& idir) {
 
 // ------------------------------------------------------------------ cull
 
+// Scenes of at most this many primitives skip the stage: every primitive is a candidate.
+#define RT_CULL_MIN_PRIMS 4u
+
 struct CullArgs {
     SceneDev  sc;
     PathQueue in;
@@ -301,12 +304,13 @@ __global__ __launch_bounds__(256) void k_cull(CullArgs a) {
 // per lane, and each wave gets 64 VGPRs.  (Measured per frame of the atrium, with the candidate
 // scan still inside this kernel: 6 waves with 24 levels 1.38 ms, 7 with 22 1.34, 8 with 20 1.39;
 // with the scan in its own kernel the lane state fits 64 registers: 7 waves 1.12 ms, 8 waves 1.10.)
-#ifndef RT_LDS_LEVELS
-#define RT_LDS_LEVELS 19u
-#endif
-#ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 8
-#endif
+// The MULTI instantiation carries more per-lane state (chunk masks) and stays at seven waves with
+// 22 levels.
+#define RT_LDS_LEVELS_SINGLE 19u
+#define RT_LDS_LEVELS_MULTI 22u
+#define RT_EXTEND_WAVES_SINGLE 8
+#define RT_EXTEND_WAVES_MULTI 7
+__host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi ? RT_LDS_LEVELS_MULTI : RT_LDS_LEVELS_SINGLE; }
 #define RT_MAX_STACK 64u
 
 // trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
@@ -335,11 +339,12 @@ __global__ __launch_bounds__(256) void k_cull(CullArgs a) {
 // touch at all (cmask), and the scan of a chunk skips the groups that no waiting lane's ray meets.
 //
 // The traversal stack is one LDS dword column per lane (stack[level][lane]: conflict-free) for
-// the first RT_LDS_LEVELS entries; the DEEP instantiation (stack_depth above that, for trees of
+// the first rt_lds_levels() entries; the DEEP instantiation (stack_depth above that, for trees of
 // tens of millions of triangles) continues in a global-memory column per thread, so that a deep
 // stack does not cost occupancy.  The reference does not re-test the box of a popped node either.
 template <bool COUNT, bool DEEP, bool MULTI>
-__global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
+__global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
+    constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
     const uint32_t lane = lane_id();
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (RT_LDS_LEVELS * RT_WAVE) + lane;
@@ -480,7 +485,8 @@ __global__ __launch_bounds__(256, RT_EXTEND_WAVES) void k_extend(ExtArgs a) {
                         o = F3(s0.x, s0.y, s0.z);
                         d = F3(s0.w, s1.x, s1.y);
                         if (!MULTI) { // the candidate mask the cull stage left in the ray's hit record
-                            const uint4 mk = *reinterpret_cast<const uint4*>(a.hits + slot);
+                            uint4 mk = make_uint4(sc.n_prims >= 32u ? ~0u : (1u << sc.n_prims) - 1u, 0u, 0u, 0u);
+                            if (!a.no_cull) mk = *reinterpret_cast<const uint4*>(a.hits + slot);
                             mask[0] = mk.x; mask[1] = mk.y; mask[2] = mk.z; mask[3] = mk.w;
                         }
                         // no hit yet; `debug` (here: the overflow flag) is reset by every trace(), shader.wgsl:602

@@ -713,8 +713,10 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     }
 
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
-    const bool deep = P.stack_depth > RT_LDS_LEVELS;
     const bool multi = c->sc.n_chunks > 1u;
+    const bool deep = P.stack_depth > rt_lds_levels(multi);
+    // with a handful of primitives the candidate test saves less than it costs
+    const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     int ext_blocks = extend_occupancy(count, deep, multi);
     if (const char* e = std::getenv("RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
         const int v = std::atoi(e);
@@ -733,7 +735,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             c->shadow_cap = c->queue_cap;
         }
         if (deep) { // stack levels beyond the LDS part: one dword column per thread of the extend grid
-            const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_LDS_LEVELS) * ext_grid * 256;
+            const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi)) * ext_grid * 256;
             if (c->spill_words < words) {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 free_dev_t(c->spill);
@@ -775,7 +777,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.nan_tri = nanw.tri;
             ea.nan_dropped = nanw.dropped;
             ea.nan_overflow = nanw.dropped ? 1u : 0u;
-            if (!multi) {
+            ea.no_cull = cull ? 0u : 1u;
+            if (cull) {
                 CullArgs ca{};
                 ca.sc = c->sc;
                 ca.in = q[b & 1];
@@ -887,13 +890,14 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     if (e != hipSuccess) { cleanup(); return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e)); }
 
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
-    const bool deep = P.stack_depth > RT_LDS_LEVELS;
-    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const bool multi = c->sc.n_chunks > 1u;
+    const bool deep = P.stack_depth > rt_lds_levels(multi);
+    const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
+    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const int blocks = extend_occupancy(count, deep, multi);
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * blocks, (n + 255) / 256);
     if (deep) {
-        const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_LDS_LEVELS) * grid * 256;
+        const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi)) * grid * 256;
         if (c->spill_words < words) {
             (void)hipStreamSynchronize(c->stream);
             free_dev_t(c->spill);
@@ -915,7 +919,8 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     ea.nan_inner = nanw.inner; ea.nan_leaf = nanw.leaf; ea.nan_tri = nanw.tri; ea.nan_dropped = nanw.dropped;
     ea.nan_overflow = nanw.dropped ? 1u : 0u;
     (void)hipGetLastError(); // not this call's
-    if (!multi) {
+    ea.no_cull = cull ? 0u : 1u;
+    if (cull) {
         CullArgs ca{};
         ca.sc = c->sc;
         ca.in = ea.in;
