@@ -300,14 +300,16 @@ __global__ __launch_bounds__(256) void k_cull(CullArgs a) {
 #define RT_PM_PRIM 0x1FFFFFFFu
 #define RT_PM_OVERFLOW 0x20000000u
 #define RT_PM_MODE_SHIFT 30
-// Eight waves per SIMD: 32 waves of a CU share its 160 KB of LDS, which leaves 19 stack levels
-// per lane, and each wave gets 64 VGPRs.  (Measured per frame of the atrium, with the candidate
-// scan still inside this kernel: 6 waves with 24 levels 1.38 ms, 7 with 22 1.34, 8 with 20 1.39;
-// with the scan in its own kernel the lane state fits 64 registers: 7 waves 1.12 ms, 8 waves 1.10.)
+// Eight waves per SIMD: 32 waves of a CU share its 160 KB of LDS, 20 dwords per lane: six hold the
+// ray's origin and direction, 13 the first levels of the traversal stack (deeper levels are rare:
+// 13 levels run as fast as 19); each wave gets 64 VGPRs.  (Measured per frame of the atrium, with
+// the candidate scan still inside this kernel: 6 waves with 24 levels 1.38 ms, 7 with 22 1.34, 8
+// with 20 1.39; with the scan in its own kernel the lane state fits 64 registers: 7 waves 1.12 ms,
+// 8 waves 1.10, with the ray in LDS instead of re-read from the queue 1.08.)
 // The MULTI instantiation carries more per-lane state (chunk masks) and stays at seven waves with
-// 22 levels.
-#define RT_LDS_LEVELS_SINGLE 19u
-#define RT_LDS_LEVELS_MULTI 22u
+// 16 levels.
+#define RT_LDS_LEVELS_SINGLE 13u
+#define RT_LDS_LEVELS_MULTI 16u
 #define RT_EXTEND_WAVES_SINGLE 8
 #define RT_EXTEND_WAVES_MULTI 7
 __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi ? RT_LDS_LEVELS_MULTI : RT_LDS_LEVELS_SINGLE; }
@@ -346,6 +348,9 @@ template <bool COUNT, bool DEEP, bool MULTI>
 __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
     constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
+    // world-space origin and direction of each lane's ray, read again at every primitive it enters
+    __shared__ float lds_ray[6 * 256];
+    float* const ray = lds_ray + threadIdx.x;
     const uint32_t lane = lane_id();
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (RT_LDS_LEVELS * RT_WAVE) + lane;
     // levels RT_LDS_LEVELS.. of a deep stack: one global dword column per thread of the grid
@@ -367,10 +372,10 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
     bool drained = false;
 
     // per-lane
-    // per-lane.  What a ray needs only between primitives stays in memory, where it lives
-    // anyway, so that more waves fit a SIMD: origin and direction in the queue record, the closest
-    // hit so far and the seed in the hit record (written at fetch, updated by every primitive that
-    // gives a closer hit, complete when the ray retires).
+    // per-lane.  What a ray needs only between primitives is not held in registers, so that more
+    // waves fit a SIMD: origin and direction in LDS, the closest hit so far and the seed in the hit
+    // record (written at fetch, updated by every primitive that gives a closer hit, complete when
+    // the ray retires).
     uint32_t st = ST_DONE;
     uint32_t slot = 0;
     uint32_t mask[4] = {0, 0, 0, 0};
@@ -491,6 +496,8 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                         }
                         // no hit yet; `debug` (here: the overflow flag) is reset by every trace(), shader.wgsl:602
                         a.hits[slot] = make_float4(99999999.0f, __int_as_float(-1), 0.0f, s1.z);
+                        ray[0] = o.x; ray[256] = o.y; ray[512] = o.z;
+                        ray[768] = d.x; ray[1024] = d.y; ray[1280] = d.z;
                         pm = 0;
                         cb = 0;
                         if (MULTI) cmask = ~0ull;
@@ -549,9 +556,8 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
             const bool mine = st == ST_SCAN && (!MULTI || cb == c0);
             f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
             if (mine) {
-                const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
-                o = F3(s0.x, s0.y, s0.z);
-                d = F3(s0.w, s1.x, s1.y);
+                o = F3(ray[0], ray[256], ray[512]);
+                d = F3(ray[768], ray[1024], ray[1280]);
             }
             // A zero direction component makes 1/d infinite and b * inf - o * inf a NaN that would
             // silently drop that axis' bound on one side only; a huge finite reciprocal keeps the
@@ -695,8 +701,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
                 else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
                 const uint32_t p = (MULTI ? cb : 0u) + k;
-                const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
-                const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
+                const f3 o = F3(ray[0], ray[256], ray[512]), d = F3(ray[768], ray[1024], ray[1280]);
                 const float closest_t = a.hits[slot].x;
                 const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
                 const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[4], r1 = pp[5]; // r0, r1: the root node
