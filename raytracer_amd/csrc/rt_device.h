@@ -9,24 +9,30 @@
 
 // ------------------------------------------------------------------ records in HBM
 
-// Extend-stage view of a primitive.  The first 96 bytes are what a lane needs when it enters the
-// primitive (six independent 16-byte loads): inv holds rows 0..2 of the four columns of the
-// uploaded inv_transform (scene.rs:185), root_node is a copy of the BVH root's record so that the
-// root test does not wait for a second, dependent fetch.
+// Extend-stage view of a primitive.  The first 80 bytes are what a lane needs when it enters the
+// primitive (five independent 16-byte loads): inv holds rows 0..2 of the four columns of the
+// uploaded inv_transform (scene.rs:185); root_box, root_first and root_word are a copy of the BVH
+// root's record, so that the root test does not wait for a second, dependent fetch, with the
+// primitive's alpha mode in the spare bits of the count.
 struct PrimX {
+    // the 80 bytes the extend stage reads when a ray enters the primitive
     float    inv[12];
-    uint32_t root;            // device node index of the BVH root
-    uint32_t alpha_settings;  // scene.rs:164, 170-177, plus RT_PRIMX_NESTED_ROOT in an unused bit
-    uint32_t albedo_offset, albedo_size;
     float    root_box[6];     // the root node: min.xyz, max.xyz,
-    uint32_t root_first, root_count; // first, count (first already in device numbering)
+    uint32_t root_first;      // first (in device numbering) and
+    uint32_t root_word;       // count in the low 28 bits, RT_PRIMX_* flags above
+    // the rest (alpha test, shadow rays)
+    uint32_t root;            // device node index of the BVH root
+    uint32_t alpha_settings;  // scene.rs:164, 170-177
+    uint32_t albedo_offset, albedo_size;
     uint32_t albedo_texcoord;
     uint32_t pad[3];
 };
 static_assert(sizeof(PrimX) == 112, "PrimX");
-// alpha_settings bit: the root is an inner node and both child boxes lie inside the root box (true
-// for every tree the reference's builder makes; checked at upload because any tree is accepted)
-#define RT_PRIMX_NESTED_ROOT 4u
+#define RT_PRIMX_COUNT_MASK 0x0FFFFFFFu
+#define RT_PRIMX_MODE_SHIFT 28   // two bits: alpha mode (alpha_settings & 3)
+// the root is an inner node and both child boxes lie inside the root box (true for every tree the
+// reference's builder makes; checked at upload because any tree is accepted)
+#define RT_PRIMX_NESTED_ROOT 0x40000000u
 
 // Uploaded records, read as-is by the shade stage.
 struct TexRefD { uint32_t offset, size; };

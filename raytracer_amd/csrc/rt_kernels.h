@@ -704,8 +704,10 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 const f3 o = F3(ray[0], ray[256], ray[512]), d = F3(ray[768], ray[1024], ray[1280]);
                 const float closest_t = a.hits[slot].x;
                 const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
-                const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[4], r1 = pp[5]; // r0, r1: the root node
-                const uint32_t settings = reinterpret_cast<const uint32_t*>(pp + 3)[1]; // alpha_settings
+                const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[3];
+                float4 r1 = pp[4]; // r0, r1: the root node, alpha mode and flags above its count
+                const uint32_t settings = __float_as_uint(r1.w);
+                r1.w = __uint_as_float(settings & RT_PRIMX_COUNT_MASK);
                 const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
                 // transform_ray + scale factor, shader.wgsl:604-607
                 const f3 td = xform_dir(d, inv);
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 ld = td / scale;
                 lo = xform_pos(o, inv);
                 lidir = rcp3(ld);
-                pm = (pm & RT_PM_OVERFLOW) | p | ((settings & 3u) << RT_PM_MODE_SHIFT);
+                pm = (pm & RT_PM_OVERFLOW) | p | (((settings >> RT_PRIMX_MODE_SHIFT) & 3u) << RT_PM_MODE_SHIFT);
                 const bool nested = (settings & RT_PRIMX_NESTED_ROOT) != 0u;
                 if (COUNT) c_prims++;
                 const float troot = hit_aabb_s(lo, lidir, r0, r1);
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_shadow(ShadowArgs a) {
             const f3 lidir = rcp3(ld);
             const float4* rp = reinterpret_cast<const float4*>(px.root_box);
             if (hit_aabb_s(lo, lidir, rp[0], rp[1]) < -0.5f) continue;
-            uint32_t first = px.root_first, count = px.root_count, sp = 0;
+            uint32_t first = px.root_first, count = px.root_word & RT_PRIMX_COUNT_MASK, sp = 0;
             for (;;) {
                 if (count > 0u) {
                     for (uint32_t i = first; i < first + count && !occluded; i++) {

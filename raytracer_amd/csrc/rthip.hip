@@ -491,9 +491,11 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
             const HostNode& rn = dev_nodes[x.root];
             std::memcpy(x.root_box, rn.aabb, sizeof x.root_box);
             x.root_first = rn.first;
-            x.root_count = rn.count;
+            if (rn.count > RT_PRIMX_COUNT_MASK)
+                return fail(c, RTHIP_ERR_UNSUPPORTED, "upload_scene: primitive %u has a root leaf of %u triangles", p, rn.count);
+            x.root_word = rn.count | ((pr.material.alpha_settings & 3u) << RT_PRIMX_MODE_SHIFT);
         }
-        x.alpha_settings = pr.material.alpha_settings & ~RT_PRIMX_NESTED_ROOT;
+        x.alpha_settings = pr.material.alpha_settings;
         {
             const HostNode& rn = dev_nodes[map[pr.bvh_idx]];
             if (rn.count == 0) {
@@ -502,7 +504,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
                     const HostNode& cn = dev_nodes[rn.first + ch];
                     for (int k = 0; k < 3; k++) inside = inside && cn.aabb[k] >= rn.aabb[k] && cn.aabb[3 + k] <= rn.aabb[3 + k];
                 }
-                if (inside) x.alpha_settings |= RT_PRIMX_NESTED_ROOT;
+                if (inside) x.root_word |= RT_PRIMX_NESTED_ROOT;
             }
         }
         x.albedo_offset = pr.material.albedo.offset;
