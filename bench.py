@@ -251,7 +251,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 # PMC counters cannot be read from inside the run; this is the figure of the committed
-                # profile of the default command (same workload, same 32-frame launches)
+                # profile of the default command (same workload, same 64-frame launches)
                 "traffic": profiled_extend_traffic() if default_run else None,
                 "traffic_source": "profiles/r01_final_extend_summary.txt" if default_run else None,
                 "launches": ext["launches"],

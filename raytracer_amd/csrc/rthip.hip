@@ -182,15 +182,15 @@ bool invert4(const double m[16], double out[16]) {
 // the thin late bounces wide enough to fill the chip; the cost is queue memory (144 bytes per
 // path).  RTHIP_FRAMES_IN_FLIGHT overrides the default.
 uint32_t frames_in_flight_limit(const rthip_ctx* c) {
-    uint32_t want = 32;
+    uint32_t want = 64;
     if (const char* e = std::getenv("RTHIP_FRAMES_IN_FLIGHT")) {
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 64) want = (uint32_t)v;
+        if (v >= 1 && v <= 128) want = (uint32_t)v;
     }
     const uint64_t slots = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
-    // 160 bytes of queues and results per path slot: at most 16 GiB, and at most half of what the
-    // device has free beyond what this context already holds for the purpose
-    uint64_t budget = 16ull << 30;
+    // 160 bytes of queues and results per path slot: at most 48 GiB (of 288), and at most half of
+    // what the device has free beyond what this context already holds for the purpose
+    uint64_t budget = 48ull << 30;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const uint64_t held = c->queue_mem ? c->queue_cap * 160ull : 0ull;

@@ -98,12 +98,12 @@ def test_config3_atrium_1080p_rows_match_oracle(ctx, atrium):
 
 
 def test_config3_frame_grouping_is_invisible(ctx, atrium):
-    """40 frames in one call (groups of 32 + 8), in groups of 7, and one frame per call give the
+    """72 frames in one call (groups of 64 + 8), in groups of 7, and one frame per call give the
     same accumulator bit for bit; so does a second run."""
     s, a = atrium
     res = (1920, 1080)
     p = device.default_params(max_bounces=4)
-    n = 40
+    n = 72
     whole = render(ctx, s, a, res, 1, n, params=p)
     again = render(ctx, s, a, res, 1, n, params=p, upload=False)
     assert np.array_equal(whole, again)

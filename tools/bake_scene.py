@@ -5,7 +5,7 @@
 
 The file holds the flat arrays the device library uploads (layout: csrc/host/cache.cpp) and is
 what `bench.py --scene` and `Scene.from_cache` read.  PNG and JPEG textures are decoded here; the
-reference's Rust host can write the same file (INTEGRATION.md shows the writer).
+reference's Rust host can write the same file (the layout is documented in csrc/host/cache.cpp).
 """
 import argparse
 import os

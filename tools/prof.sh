@@ -6,7 +6,7 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 32 --warmup 32 --no-cpu-baseline $*"
+ARGS="--steps 64 --warmup 64 --no-cpu-baseline $*"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.log"; exit 1; }
 pass() { # name counters...
   local name=$1; shift

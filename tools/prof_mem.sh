@@ -6,7 +6,7 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/profmem_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 32 --warmup 32 --no-cpu-baseline $*"
+ARGS="--steps 64 --warmup 64 --no-cpu-baseline $*"
 pass() { # name counters...
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pmc pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
