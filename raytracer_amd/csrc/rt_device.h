@@ -56,6 +56,10 @@ static_assert(sizeof(PrimitiveD) == 240, "PrimitiveD");
 
 struct SceneDev {
     const float4*     nodes;    // 2 float4 per 32-byte node: (min.xyz,max.x)(max.y,max.z,first,count)
+    // what an inner-node step reads: per sibling pair (children first, first + 1 of an inner node)
+    // 56 bytes at byte offset 32 * first: the two boxes (min.xyz, max.xyz each) and one descriptor
+    // dword per child in the format of a traversal stack entry
+    const float4*     pairs;
     const float4*     tris;     // 3 float4 per triangle: (p0,0)(e1,0)(e2,0)
     const float4*     exts;     // 6 float4 per triangle: 3 x {uv0, uv1 | oct normal, colour, pad}
     const PrimX*      primx;

@@ -292,6 +292,19 @@ __global__ __launch_bounds__(256) void k_cull(CullArgs a) {
     }
 }
 
+// intersect_aabb on six separate bounds (the sibling-pair records), same arithmetic as hit_aabb_s
+__device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, float nz, float xx, float xy, float xz) {
+    const float d0x = nx - o.x, d0y = ny - o.y, d0z = nz - o.z;
+    const float d1x = xx - o.x, d1y = xy - o.y, d1z = xz - o.z;
+    const bool inside = fmaxf(d0x, fmaxf(d0y, d0z)) <= 0.0f && fminf(d1x, fminf(d1y, d1z)) > 0.0f;
+    const float ax = d0x * idir.x, ay = d0y * idir.y, az = d0z * idir.z;
+    const float bx = d1x * idir.x, by = d1y * idir.y, bz = d1z * idir.z;
+    const float t0 = fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float t1 = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    const float r = (t0 > t1 || t0 < 0.0f) ? -1.0f : t0;
+    return inside ? 0.0f : r;
+}
+
 // A traversal stack entry is the (first, count) pair of the postponed node packed into one
 // dword when it fits (count < 16, first < 2^27), so that a pop needs no memory access; otherwise
 // bit 31 is set and the low bits are the node's index, whose record the pop re-reads.
@@ -439,19 +452,22 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
         st = count > 0u ? ST_LEAF : ST_INNER;
         if (COUNT && count > 0u) c_leaf++;
     };
+    // enter the node a descriptor (stack entry format) names
+    auto enter_desc = [&](uint32_t e) {
+        uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
+        if (e & RT_STACK_RELOAD) {
+            const float4 q = rec16(nodes, (e & 0x7FFFFFFFu) * 2u)[1];
+            first = __float_as_uint(q.z);
+            count = __float_as_uint(q.w);
+        }
+        enter(first, count);
+    };
     auto pop_or_finish = [&]() {
         if (sp == 0u) {
             finish();
         } else {
             --sp;
-            const uint32_t e = (DEEP && sp >= RT_LDS_LEVELS) ? spill_at(sp) : stack[sp * RT_WAVE];
-            uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
-            if (e & RT_STACK_RELOAD) {
-                const float4 q = rec16(nodes, (e & 0x7FFFFFFFu) * 2u)[1];
-                first = __float_as_uint(q.z);
-                count = __float_as_uint(q.w);
-            }
-            enter(first, count);
+            enter_desc((DEEP && sp >= RT_LDS_LEVELS) ? spill_at(sp) : stack[sp * RT_WAVE]);
         }
     };
 
@@ -610,10 +626,12 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 if (COUNT) r_inner++;
                 if (st == ST_INNER) {
                     if (COUNT) c_inner++;
-                    const float4* np = rec16(nodes, cur_first * 2u); // siblings: one aligned 64-byte fetch
-                    const float4 l0 = np[0], l1 = np[1], q0 = np[2], q1 = np[3];
-                    const float left = hit_aabb_s(lo, lidir, l0, l1);
-                    const float right = hit_aabb_s(lo, lidir, q0, q1);
+                    // the sibling pair: 48 bytes of boxes and a descriptor dword per child
+                    const float4* np = rec16(sc.pairs, cur_first * 2u);
+                    const float4 b0 = np[0], b1 = np[1], b2 = np[2];
+                    const uint2 dsc = *reinterpret_cast<const uint2*>(np + 3);
+                    const float left = hit_aabb6(lo, lidir, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+                    const float right = hit_aabb6(lo, lidir, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w);
                     const bool lmiss = (left < -0.5f || left > best_t);
                     const bool rmiss = (right < -0.5f || right > best_t);
                     if (lmiss && rmiss) {
@@ -622,16 +640,14 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                         const bool go_left = rmiss ? true : (lmiss ? false : left < right);
                         if (!lmiss && !rmiss) {
                             if (sp < depth) {
-                                const uint32_t ff = __float_as_uint(go_left ? q1.z : l1.z), fc = __float_as_uint(go_left ? q1.w : l1.w);
-                                const uint32_t nd = go_left ? cur_first + 1u : cur_first;
-                                const uint32_t e = (fc < 16u && ff < 0x08000000u) ? (ff | (fc << 27)) : (RT_STACK_RELOAD | nd);
+                                const uint32_t e = go_left ? dsc.y : dsc.x; // the far child, postponed
                                 if (DEEP && sp >= RT_LDS_LEVELS) spill_at(sp) = e;
                                 else stack[sp * RT_WAVE] = e;
                                 sp++;
                             }
                             else { pm |= RT_PM_OVERFLOW; if (COUNT) c_over++; } // shader.wgsl:306-313
                         }
-                        enter(__float_as_uint(go_left ? l1.z : q1.z), __float_as_uint(go_left ? l1.w : q1.w));
+                        enter_desc(go_left ? dsc.x : dsc.y);
                     }
                 }
                 if (__ballot(st == ST_INNER) == 0ull) break;

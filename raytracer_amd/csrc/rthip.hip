@@ -50,6 +50,7 @@ struct rthip_ctx {
     void*     d_primx = nullptr;
     void*     d_wbounds = nullptr;
     void*     d_gbounds = nullptr;
+    void*     d_pairs = nullptr;
     void*     d_cbounds = nullptr;
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
@@ -135,7 +136,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_cbounds);
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_cbounds);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -463,6 +464,26 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     }
     // padding records stay zero; nothing references them
 
+    // Sibling-pair records for the inner-node step: boxes of the two children and a descriptor
+    // each, at the position of the first child.  A node with two parents would make two records
+    // overlap; the reference's builder cannot produce one.
+    std::vector<uint32_t> pairs((size_t)n_dev_nodes * 8, 0u);
+    {
+        std::vector<uint8_t> claimed(n_dev_nodes, 0);
+        for (uint64_t i = 0; i < n_dev_nodes; i++) {
+            const HostNode& n = dev_nodes[i];
+            if (n.count != 0 || n.first == 0) continue; // leaves and padding
+            for (uint32_t ch = 0; ch < 2; ch++) {
+                const uint64_t ci = (uint64_t)n.first + ch;
+                if (claimed[ci]) return fail(c, RTHIP_ERR_INVALID, "upload_scene: node %llu (device numbering) is the child of two nodes: not a tree", (unsigned long long)ci);
+                claimed[ci] = 1;
+                const HostNode& cn = dev_nodes[ci];
+                std::memcpy(&pairs[(size_t)n.first * 8 + 6 * ch], cn.aabb, 24);
+                pairs[(size_t)n.first * 8 + 12 + ch] = (cn.count < 16u && cn.first < 0x08000000u) ? (cn.first | (cn.count << 27)) : (RT_STACK_RELOAD | (uint32_t)ci);
+            }
+        }
+    }
+
     // Triangles: (p0, e1, e2); the edges are the same f32 subtractions the shader performs per
     // test (shader.wgsl:340-341), done once.  Order = uploaded order.
     std::vector<float> dev_tris((size_t)s->n_tris * 12);
@@ -578,6 +599,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         return e;
     };
     HIP_TRY(c, upload(c->d_nodes, dev_nodes.data(), sizeof(HostNode) * n_dev_nodes));
+    HIP_TRY(c, upload(c->d_pairs, pairs.data(), sizeof(uint32_t) * pairs.size()));
     HIP_TRY(c, upload(c->d_tris, dev_tris.data(), sizeof(float) * dev_tris.size()));
     HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
     HIP_TRY(c, upload(c->d_wbounds, wbounds.data(), sizeof(float) * wbounds.size()));
@@ -594,6 +616,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->sc.primx = static_cast<const PrimX*>(c->d_primx);
     c->sc.wbounds = static_cast<const float*>(c->d_wbounds);
     c->sc.n_prim_groups = n_prim_groups;
+    c->sc.pairs = static_cast<const float4*>(c->d_pairs);
     c->sc.gbounds = static_cast<const float*>(c->d_gbounds);
     c->sc.cbounds = static_cast<const float*>(c->d_cbounds);
     c->sc.n_chunks = n_chunks;
