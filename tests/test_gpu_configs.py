@@ -223,3 +223,31 @@ def test_many_primitives_span_several_chunks(ctx):
         assert q["tri"][i] == tri, i
         if tri >= 0:
             assert q["prim"][i] == prim and q["t"][i] == np.float32(t), i
+
+
+@pytest.mark.parametrize("tiles,n_prims", [(2, 8), (4, 32), (8, 128), (9, 162)])
+def test_primitive_counts_around_the_candidate_mask_limits(ctx, tiles, n_prims):
+    """8 and 32 primitives (one mask word, cull stage), 128 (all four words, the last scene the cull
+    stage serves) and 162 (two chunks, in-kernel scan): frames against the oracle, which tests every
+    primitive."""
+    s = procedural.terrain_scene(tiles=tiles, n=16, env_size=(64, 32), instanced=True)
+    a = s.arrays()
+    assert a["prims"].shape[0] == n_prims
+    res = (160, 90)
+    p = device.default_params(max_bounces=3)
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=5, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(5, 2, 1, p)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    ref = orc.render(oracle_scene(a), u, oracle_params(p), 5, 2, 1, taps=True, n_threads=THREADS)
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.9995
+    hit = (got["tri"] >= 0) & (got["tri"] == ref["tri"])
+    assert np.array_equal(got["prim"][hit], ref["prim"][hit])
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.998
+    same = got["seed"] == ref["seed"]
+    np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
+    for k in ("inner_steps", "tri_tests"):
+        assert abs(got["counters"][k] - ref["counters"][k]) <= max(16, 3e-3 * ref["counters"][k]), k
