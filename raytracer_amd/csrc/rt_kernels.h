@@ -119,9 +119,7 @@ __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
         s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(fs * a.n_pixels + px + a.res_x * py));
     }
     a.out.s0[gid] = s0;
-    a.out.s1[gid] = s1;
-    a.out.s2[gid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    a.out.s3[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    a.out.s1[gid] = s1; // throughput (1) and lighting (0) are implied for camera paths
     if (a.counters) {
         const unsigned long long n = wave_sum(valid ? 1ull : 0ull);
         if (lane_id() == 0 && n) atomicAdd(&a.counters[C_PATHS], n);
@@ -786,8 +784,8 @@ struct ShadeArgs {
     uint32_t* tap_seed;     // null unless taps are on for this launch
     float     term_prob;
     uint32_t  last_bounce;  // 1: survivors of this bounce end here (loop bound, shader.wgsl:898)
+    uint32_t  first_bounce; // 1: the queue holds camera paths (throughput 1, lighting 0: planes s2, s3 are not written)
     uint32_t  n_pixels;
-    uint32_t  pad;
     unsigned long long* counters;
 };
 
@@ -836,7 +834,10 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         bool survive = false, to_shadow = false;
         float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
         if (slot < n && __float_as_uint(a.in.s1[slot].w) != RT_NO_PIXEL) {
-            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
+            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+            // camera paths all start with throughput 1 and no light gathered: not stored, not read
+            float4 s2 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (!a.first_bounce) { s2 = a.in.s2[slot]; s3 = a.in.s3[slot]; }
             const float4 h = a.hits[slot];
             f3 origin = F3(s0.x, s0.y, s0.z), dir = F3(s0.w, s1.x, s1.y);
             f3 thr = F3(s2.x, s2.y, s2.z), lit = F3(s3.x, s3.y, s3.z);

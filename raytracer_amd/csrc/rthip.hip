@@ -827,6 +827,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             sa.tap_seed = tap_group ? c->tap_seed : nullptr;
             sa.term_prob = P.term_prob;
             sa.last_bounce = (b + 1 == P.max_bounces) ? 1u : 0u;
+            sa.first_bounce = (b == 0) ? 1u : 0u;
             sa.n_pixels = (uint32_t)c->n_pixels;
             sa.counters = c->d_counters;
             {
