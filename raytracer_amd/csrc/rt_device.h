@@ -72,6 +72,9 @@ struct SceneDev {
     // and of every chunk of 128, for scenes of more than one chunk
     const float*      gbounds;
     const float*      cbounds;
+    // the same padded bounds, one 32-byte record per primitive (min.xyz, max.xyz, 0, 0), for the
+    // camera-ray cull, which looks at single primitives
+    const float*      pbounds;
     const PrimitiveD* prims;
     const uint32_t*   texels;
     const float4*     env;

@@ -290,6 +290,96 @@ __global__ __launch_bounds__(256) void k_cull(CullArgs a) {
     }
 }
 
+__device__ __forceinline__ float wave_min_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// The cull stage for camera rays.  A wave's 64 queue slots are one 8x8 pixel tile of one frame:
+// rays from nearly one point into a narrow pyramid.  The wave first bounds its rays (origin box,
+// direction box) and asks, one primitive per lane, which primitives that set of rays can meet at
+// all -- the slab test in interval arithmetic: per axis a lower bound L of every ray's entry
+// distance and an upper bound U of its exit distance; no ray meets the box if some axis' L is
+// above another's U, or an exit lies behind the origin -- and then runs the exact per-ray test of
+// k_cull for those primitives only (a tenth of them on the atrium).  The interval test is
+// conservative: its bounds are widened beyond f32 rounding, and an axis on which the directions
+// straddle (or come close to) zero puts no constraint.  The masks are those k_cull computes.
+__global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
+    const uint32_t n = *a.count_in;
+    const SceneDev& sc = a.sc;
+    const uint32_t lane = lane_id();
+    const float inf = __builtin_inff();
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t slot = base + lane;
+        f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+        bool live = false;
+        if (slot < n) {
+            const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+            live = __float_as_uint(s1.w) != RT_NO_PIXEL;
+            o = F3(s0.x, s0.y, s0.z);
+            d = F3(s0.w, s1.x, s1.y);
+        }
+        f3 oi, idir;
+        world_test_ray(o, d, oi, idir);
+        if (__ballot(live) == 0ull) continue;
+        // the box of the wave's origins and of its directions
+        const float on[3] = {wave_min_f(live ? o.x : inf), wave_min_f(live ? o.y : inf), wave_min_f(live ? o.z : inf)};
+        const float ox[3] = {wave_max_f(live ? o.x : -inf), wave_max_f(live ? o.y : -inf), wave_max_f(live ? o.z : -inf)};
+        const float dn[3] = {wave_min_f(live ? d.x : inf), wave_min_f(live ? d.y : inf), wave_min_f(live ? d.z : inf)};
+        const float dx[3] = {wave_max_f(live ? d.x : -inf), wave_max_f(live ? d.y : -inf), wave_max_f(live ? d.z : -inf)};
+        unsigned long long cand[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const uint32_t q = lane + 64u * pass;
+            const bool valid = q < sc.n_prims;
+            float b[6] = {0, 0, 0, 0, 0, 0};
+            if (valid) {
+                const float4 b0 = reinterpret_cast<const float4*>(sc.pbounds)[2u * q], b1 = reinterpret_cast<const float4*>(sc.pbounds)[2u * q + 1u];
+                b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y;
+            }
+            float l_max = -inf, u_min = inf;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (dn[k] > 1e-30f || dx[k] < -1e-30f) { // wave-uniform
+                    const float i0 = 1.0f / dx[k], i1 = 1.0f / dn[k];
+                    const float n0 = b[k] - ox[k], n1 = b[k] - on[k], n2 = b[3 + k] - ox[k], n3 = b[3 + k] - on[k];
+                    const float p0 = n0 * i0, p1 = n0 * i1, p2 = n1 * i0, p3 = n1 * i1;
+                    const float p4 = n2 * i0, p5 = n2 * i1, p6 = n3 * i0, p7 = n3 * i1;
+                    float lo = fminf(fminf(fminf(p0, p1), fminf(p2, p3)), fminf(fminf(p4, p5), fminf(p6, p7)));
+                    float hi = fmaxf(fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)), fmaxf(fmaxf(p4, p5), fmaxf(p6, p7)));
+                    lo -= fabsf(lo) * 1e-5f + 1e-6f;
+                    hi += fabsf(hi) * 1e-5f + 1e-6f;
+                    l_max = fmaxf(l_max, lo);
+                    u_min = fminf(u_min, hi);
+                }
+            }
+            const bool no_ray_meets = l_max > u_min || u_min < 0.0f;
+            cand[pass] = __ballot(valid && !no_ray_meets);
+        }
+        // the exact test, per ray, for the primitives that are left
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            unsigned long long bits = cand[pass];
+            while (bits) {
+                const uint32_t p = (uint32_t)__builtin_ctzll(bits) + 64u * pass;
+                bits &= bits - 1ull;
+                const rt_float8 u = *(rt_cfloat8_p)(sc.pbounds + (size_t)p * 8u);
+                const float pb[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
+                const uint32_t bit = overlaps_world_box(oi, idir, pb) ? (1u << (p & 31u)) : 0u;
+                const uint32_t w = (p >> 5) & 1u;
+                if (pass == 0) { if (w == 0u) m0 |= bit; else m1 |= bit; }
+                else { if (w == 0u) m2 |= bit; else m3 |= bit; }
+            }
+        }
+        if (live) a.masks[slot] = make_uint4(m0, m1, m2, m3);
+    }
+}
+
 // intersect_aabb on six separate bounds (the sibling-pair records), same arithmetic as hit_aabb_s
 __device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, float nz, float xx, float xy, float xz) {
     const float d0x = nx - o.x, d0y = ny - o.y, d0z = nz - o.z;

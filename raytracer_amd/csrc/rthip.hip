@@ -51,6 +51,7 @@ struct rthip_ctx {
     void*     d_wbounds = nullptr;
     void*     d_gbounds = nullptr;
     void*     d_pairs = nullptr;
+    void*     d_pbounds = nullptr;
     void*     d_cbounds = nullptr;
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
@@ -136,7 +137,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_cbounds);
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_pbounds); free_dev(c->d_cbounds);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -501,6 +502,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     std::vector<PrimX> primx(s->n_prims);
     const uint32_t n_prim_groups = (s->n_prims + 7u) / 8u;
     std::vector<float> wbounds((size_t)n_prim_groups * 48, 0.0f); // padding slots stay zero; the scan masks them off
+    std::vector<float> pbounds((size_t)s->n_prims * 8, 0.0f);
     for (uint32_t p = 0; p < s->n_prims; p++) {
         const PrimitiveD& pr = prims[p];
         PrimX& x = primx[p];
@@ -568,6 +570,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         }
         float* grp = &wbounds[(size_t)(p >> 3) * 48];
         for (int k = 0; k < 6; k++) grp[k * 8 + (p & 7u)] = wb[k];
+        for (int k = 0; k < 6; k++) pbounds[(size_t)p * 8 + k] = wb[k];
     }
 
     // union bounds per group of 8 and per chunk of 128 primitives
@@ -604,6 +607,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     HIP_TRY(c, upload(c->d_primx, primx.data(), sizeof(PrimX) * primx.size()));
     HIP_TRY(c, upload(c->d_wbounds, wbounds.data(), sizeof(float) * wbounds.size()));
     HIP_TRY(c, upload(c->d_gbounds, gbounds.data(), sizeof(float) * gbounds.size()));
+    HIP_TRY(c, upload(c->d_pbounds, pbounds.data(), sizeof(float) * pbounds.size()));
     HIP_TRY(c, upload(c->d_cbounds, cbounds.data(), sizeof(float) * cbounds.size()));
     HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
     HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
@@ -617,6 +621,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->sc.wbounds = static_cast<const float*>(c->d_wbounds);
     c->sc.n_prim_groups = n_prim_groups;
     c->sc.pairs = static_cast<const float4*>(c->d_pairs);
+    c->sc.pbounds = static_cast<const float*>(c->d_pbounds);
     c->sc.gbounds = static_cast<const float*>(c->d_gbounds);
     c->sc.cbounds = static_cast<const float*>(c->d_cbounds);
     c->sc.n_chunks = n_chunks;
@@ -742,6 +747,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     const bool deep = P.stack_depth > rt_lds_levels(multi);
     // with a handful of primitives the candidate test saves less than it costs
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
+    bool cull_camera = true;
+    if (const char* e = std::getenv("RTHIP_CULL_CAMERA")) cull_camera = std::atoi(e) != 0; // diagnostic: 0 = the general cull kernel for camera rays too
     int ext_blocks = extend_occupancy(count, deep, multi);
     if (const char* e = std::getenv("RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
         const int v = std::atoi(e);
@@ -810,7 +817,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 ca.masks = reinterpret_cast<uint4*>(c->hits);
                 ca.count_in = c->ctrl + b;
                 StageTimer t(c, timing, RTHIP_STAGE_CULL);
-                hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
+                // camera rays: a wave's slots are one pixel tile, whose rays meet few primitives
+                if (b == 0 && cull_camera) hipLaunchKernelGGL(k_cull_camera, dim3(shade_grid), dim3(256), 0, c->stream, ca);
+                else hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
             }
             {
                 StageTimer t(c, timing, RTHIP_STAGE_EXTEND);

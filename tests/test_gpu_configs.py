@@ -251,3 +251,32 @@ def test_primitive_counts_around_the_candidate_mask_limits(ctx, tiles, n_prims):
     np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
     for k in ("inner_steps", "tri_tests"):
         assert abs(got["counters"][k] - ref["counters"][k]) <= max(16, 3e-3 * ref["counters"][k]), k
+
+
+def test_camera_cull_gives_the_masks_of_the_general_cull(ctx, atrium):
+    """The wave-level interval pre-filter of the camera-ray cull must never drop a primitive a ray
+    meets: counters (prims_visited counts the mask bits) and results are identical with and
+    without it, at full size, over several frames, with depth of field."""
+    s, a = atrium
+    res = (1920, 1080)
+    p = device.default_params(max_bounces=2)
+    p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
+    out = {}
+    old = os.environ.get("RTHIP_CULL_CAMERA")
+    try:
+        for mode in ("0", "1"):
+            os.environ["RTHIP_CULL_CAMERA"] = mode
+            ctx.upload_scene(a)
+            ctx.set_frame_uniforms(s.frame_uniforms(res, frame=3, reject_hist=1))
+            ctx.reset_counters()
+            ctx.render(3, 6, 1, p)
+            out[mode] = (ctx.read_accum(), ctx.counters(), ctx.read_taps())
+    finally:
+        if old is None:
+            del os.environ["RTHIP_CULL_CAMERA"]
+        else:
+            os.environ["RTHIP_CULL_CAMERA"] = old
+    for k in ("rays", "prims_visited", "inner_steps", "tri_tests", "alpha_tests", "misses"):
+        assert out["0"][1][k] == out["1"][1][k], k
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert np.array_equal(out["0"][2]["tri"], out["1"][2]["tri"])
