@@ -305,7 +305,7 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // all -- the slab test in interval arithmetic: per axis a lower bound L of every ray's entry
 // distance and an upper bound U of its exit distance; no ray meets the box if some axis' L is
 // above another's U, or an exit lies behind the origin -- and then runs the exact per-ray test of
-// k_cull for those primitives only (a tenth of them on the atrium).  The interval test is
+// k_cull for those primitives only.  The interval test is
 // conservative: its bounds are widened beyond f32 rounding, and an axis on which the directions
 // straddle (or come close to) zero puts no constraint.  The masks are those k_cull computes.
 __global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
