@@ -83,7 +83,13 @@ struct SceneDev {
     uint32_t          n_prims;
     uint32_t          n_prim_groups;  // ceil(n_prims / 8)
     uint32_t          n_chunks;       // ceil(n_prims / 128)
+    // scenes of more than 64 chunks: 2^chunk_shift consecutive chunks form a super-chunk, so that
+    // there are at most 64 of them (n_super), with union bounds of their own (sbounds; = cbounds
+    // when chunk_shift is 0)
+    uint32_t          chunk_shift;
+    uint32_t          n_super;
     uint32_t          pad;
+    const float*      sbounds;
 };
 
 // Path state: four float4 streams per queue slot, so every access is a 16-byte-per-lane,

@@ -508,13 +508,18 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
         if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) {
             st = ST_PRIM;
         } else {
-            // the next chunk whose union bound the ray meets (chunks past the 64th are not
-            // summarised in cmask and are all visited)
+            // the next chunk: the one that follows inside the same super-chunk, else the first of
+            // the next super-chunk whose union bound the ray meets (cmask)
             if (MULTI) {
                 uint32_t next = (cb >> 7) + 1u;
-                if (next < 64u) {
-                    const unsigned long long rest = cmask >> next;
-                    next = rest ? next + (uint32_t)__builtin_ctzll(rest) : 64u;
+                const uint32_t sh = sc.chunk_shift;
+                if ((next & ((1u << sh) - 1u)) == 0u) {
+                    uint32_t sup = next >> sh;
+                    if (sup < 64u) {
+                        const unsigned long long rest = cmask >> sup;
+                        sup = rest ? sup + (uint32_t)__builtin_ctzll(rest) : 64u;
+                    }
+                    next = sup << sh;
                 }
                 cb = next * 128u;
                 if (cb < sc.n_prims) st = ST_SCAN;
@@ -629,23 +634,23 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                     }
                 }
                 run_next += min(avail, n_done);
-                // scenes of more than one chunk: which chunks can the new rays touch at all
-                // (wave-uniform over the chunks' union bounds, scalar loads)
+                // scenes of more than one chunk: which (super-)chunks can the new rays touch at all
+                // (wave-uniform over their union bounds, scalar loads)
                 if (MULTI) {
                     const f3 r = rcp3(d);
                     const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
                     const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
                     unsigned long long cm = 0ull;
-                    const uint32_t nc = min(sc.n_chunks, 64u);
+                    const uint32_t nc = min(sc.n_super, 64u);
                     for (uint32_t ch = 0; ch < nc; ch++) {
-                        const rt_float8 u = *(rt_cfloat8_p)(sc.cbounds + (size_t)ch * 8u);
+                        const rt_float8 u = *(rt_cfloat8_p)(sc.sbounds + (size_t)ch * 8u);
                         const float b[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
                         cm |= (overlaps_world_box(oi, idir, b) ? 1ull : 0ull) << ch;
                     }
                     if (nc < 64u) cm |= ~0ull << nc; // never 0: the chunks that do not exist end the walk
                     if (fresh && st == ST_SCAN) {
                         cmask = cm;
-                        cb = (uint32_t)__builtin_ctzll(cm) * 128u;
+                        cb = ((uint32_t)__builtin_ctzll(cm) << sc.chunk_shift) * 128u;
                         if (cb >= sc.n_prims) retire();
                     }
                 }
@@ -669,6 +674,19 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
             const f3 r = rcp3(d);
             const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
             const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+            // inside a super-chunk of several chunks: a chunk that none of the waiting rays meets
+            // is passed over as a whole
+            if (sc.chunk_shift != 0u) {
+                const rt_float8 u = *(rt_cfloat8_p)(sc.cbounds + (size_t)(c0 >> 7) * 8u);
+                const float ub[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
+                if (__ballot(mine && overlaps_world_box(oi, idir, ub)) == 0ull) {
+                    if (mine) {
+                        mask[0] = 0u; mask[1] = 0u; mask[2] = 0u; mask[3] = 0u;
+                        advance();
+                    }
+                    continue;
+                }
+            }
             // bounds come eight primitives at a time: six 32-byte scalar loads per group; in
             // scenes of more than one chunk a group whose union bound no waiting lane meets is
             // skipped as a whole

@@ -53,6 +53,7 @@ struct rthip_ctx {
     void*     d_pairs = nullptr;
     void*     d_pbounds = nullptr;
     void*     d_cbounds = nullptr;
+    void*     d_sbounds = nullptr;
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
     void*     d_env = nullptr;
@@ -137,7 +138,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_pbounds); free_dev(c->d_cbounds);
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_pbounds); free_dev(c->d_cbounds); free_dev(c->d_sbounds);
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -592,6 +593,21 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         }
     }
 
+    // at most 64 super-chunks of 2^chunk_shift chunks each
+    uint32_t chunk_shift = 0;
+    while (((n_chunks + (1u << chunk_shift) - 1u) >> chunk_shift) > 64u) chunk_shift++;
+    const uint32_t n_super = (n_chunks + (1u << chunk_shift) - 1u) >> chunk_shift;
+    std::vector<float> sbounds((size_t)n_super * 8, 0.0f);
+    {
+        const float big = std::numeric_limits<float>::infinity();
+        for (uint32_t su = 0; su < n_super; su++) for (int k = 0; k < 3; k++) { sbounds[(size_t)su * 8 + k] = big; sbounds[(size_t)su * 8 + 3 + k] = -big; }
+        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+            float* sb = &sbounds[(size_t)(ch >> chunk_shift) * 8];
+            const float* cb = &cbounds[(size_t)ch * 8];
+            for (int k = 0; k < 3; k++) { sb[k] = std::min(sb[k], cb[k]); sb[3 + k] = std::max(sb[3 + k], cb[3 + k]); }
+        }
+    }
+
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -609,6 +625,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     HIP_TRY(c, upload(c->d_gbounds, gbounds.data(), sizeof(float) * gbounds.size()));
     HIP_TRY(c, upload(c->d_pbounds, pbounds.data(), sizeof(float) * pbounds.size()));
     HIP_TRY(c, upload(c->d_cbounds, cbounds.data(), sizeof(float) * cbounds.size()));
+    HIP_TRY(c, upload(c->d_sbounds, sbounds.data(), sizeof(float) * sbounds.size()));
     HIP_TRY(c, upload(c->d_exts, s->tri_exts, (size_t)96 * s->n_tris));
     HIP_TRY(c, upload(c->d_prims, s->prims, (size_t)240 * s->n_prims));
     HIP_TRY(c, upload(c->d_texels, s->texels, sizeof(uint32_t) * s->n_texels));
@@ -625,6 +642,9 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->sc.gbounds = static_cast<const float*>(c->d_gbounds);
     c->sc.cbounds = static_cast<const float*>(c->d_cbounds);
     c->sc.n_chunks = n_chunks;
+    c->sc.chunk_shift = chunk_shift;
+    c->sc.n_super = n_super;
+    c->sc.sbounds = static_cast<const float*>(c->d_sbounds);
     c->sc.prims = static_cast<const PrimitiveD*>(c->d_prims);
     c->sc.texels = static_cast<const uint32_t*>(c->d_texels);
     c->sc.env = static_cast<const float4*>(c->d_env);

@@ -280,3 +280,40 @@ def test_camera_cull_gives_the_masks_of_the_general_cull(ctx, atrium):
         assert out["0"][1][k] == out["1"][1][k], k
     assert np.array_equal(out["0"][0], out["1"][0])
     assert np.array_equal(out["0"][2]["tri"], out["1"][2]["tri"])
+
+
+def test_ten_thousand_primitives_use_super_chunks(ctx):
+    """10 368 instanced primitives = 81 chunks of 128, more than the 64 bits of a ray's chunk mask:
+    pairs of chunks form super-chunks.  Single rays bit for bit and a frame against the oracle."""
+    s = procedural.terrain_scene(tiles=72, n=8, env_size=(64, 32), instanced=True)
+    a = s.arrays()
+    assert a["prims"].shape[0] == 10368
+    ctx.upload_scene(a)
+    sc = oracle_scene(a)
+    rng = np.random.default_rng(11)
+    n = 300
+    o = np.column_stack([rng.uniform(-1400, 1400, n), rng.uniform(-1400, 1400, n), rng.uniform(0.5, 40, n)]).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 2] -= 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q = ctx.trace_rays(o, d)
+    op = oracle_params(device.default_params())
+    hits = 0
+    for i in range(n):
+        tri, prim, t, _ = orc.trace_ray(sc, o[i], d[i], op, 0)
+        assert q["tri"][i] == tri, i
+        if tri >= 0:
+            hits += 1
+            assert q["prim"][i] == prim and q["t"][i] == np.float32(t), i
+    assert hits > n // 4
+    res = (96, 54)
+    p = device.default_params(max_bounces=2)
+    p.flags |= device.FLAG_TAPS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1)
+    ctx.set_frame_uniforms(u)
+    ctx.render(1, 1, 1, p)
+    got = ctx.read_taps()
+    ref = orc.render(sc, u, oracle_params(p), 1, 1, 1, taps=True, n_threads=THREADS)
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.999
+    hit = (got["tri"] >= 0) & (got["tri"] == ref["tri"])
+    assert np.array_equal(got["prim"][hit], ref["prim"][hit])
