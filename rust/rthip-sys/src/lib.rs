@@ -60,6 +60,16 @@ pub struct rthip_counters {
     pub shadow_rays: u64,
 }
 
+/// Mirrors `rthip_timing`: summed kernel time and launch count per stage
+/// (generate, extend, shade, resolve, accumulate, shadow, cull).
+pub const RTHIP_NUM_STAGES: usize = 7;
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct rthip_timing {
+    pub ms: [f64; RTHIP_NUM_STAGES],
+    pub launches: [u64; RTHIP_NUM_STAGES],
+}
+
 pub const RTHIP_FLAG_COUNTERS: u32 = 1;
 pub const RTHIP_FLAG_TAPS: u32 = 2;
 pub const RTHIP_FLAG_TIMING: u32 = 4;
@@ -93,6 +103,8 @@ extern "C" {
     pub fn rthip_resolve(ctx: *mut rthip_ctx, rgba8: *mut u8, n_pixels: u64, apply_srgb_oetf: c_int) -> c_int;
     pub fn rthip_get_counters(ctx: *mut rthip_ctx, out: *mut rthip_counters) -> c_int;
     pub fn rthip_reset_counters(ctx: *mut rthip_ctx) -> c_int;
+    pub fn rthip_get_timing(ctx: *mut rthip_ctx, out: *mut rthip_timing) -> c_int;
+    pub fn rthip_reset_timing(ctx: *mut rthip_ctx) -> c_int;
     pub fn rthip_synchronize(ctx: *mut rthip_ctx) -> c_int;
 }
 
