@@ -105,8 +105,8 @@ def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="atrium")
     ap.add_argument("--scene", default=None, help="path of a .rtscene file to render instead of a procedural workload")
     ap.add_argument("--res", default="1920x1080")
@@ -207,7 +207,7 @@ def main():
 
     copy_gbs = ctx.copy_bandwidth() if rank == 0 else 0.0
     default_run = (args.scene is None and args.workload == "atrium" and args.res == "1920x1080" and args.max_bounces == 4 and args.detail == 1.0
-                   and args.tex == 1024 and K % 32 == 0 and not args.opaque and os.environ.get("RTHIP_FRAMES_IN_FLIGHT") is None)
+                   and args.tex == 1024 and K % 64 == 0 and not args.opaque and os.environ.get("RTHIP_FRAMES_IN_FLIGHT") is None)
     if rank == 0:
         ext = timing["extend"]
         ext_bytes = extend_algorithmic_bytes(counters)
