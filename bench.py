@@ -57,6 +57,34 @@ def profiled_extend_traffic():
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
+PIPELINE_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_extend_memory_pipeline.txt")
+
+
+def profiled_extend_units():
+    """Busy fractions of the CU's vector-memory units during k_extend, from the committed PMC pass
+    of the default command (tools/prof_mem.sh): busy cycles summed over the 256 CUs / (cycles of the
+    dispatch x 256).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.  None when the summary is missing."""
+    try:
+        text = open(PIPELINE_SUMMARY).read()
+    except OSError:
+        return None
+    block = text.split("\n  void k_extend<false, true, false>(ExtArgs)\n")
+    if len(block) < 2:
+        return None
+    vals = {}
+    for line in block[-1].split("\n\n")[0].splitlines():
+        f = line.split()
+        if len(f) >= 5 and f[0] in ("GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum", "TD_TD_BUSY_sum", "TD_TC_STALL_sum"):
+            vals[f[0]] = float(f[-1])
+    if len(vals) != 4 or vals["GRBM_GUI_ACTIVE"] <= 0:
+        return None
+    cu_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
+    return {"address_unit_busy": round(vals["TA_TA_BUSY_sum"] / cu_cycles, 3),
+            "data_return_busy": round(vals["TD_TD_BUSY_sum"] / cu_cycles, 3),
+            "data_return_stalled_on_l1_miss": round(vals["TD_TC_STALL_sum"] / cu_cycles, 3),
+            "source": "profiles/r01_final_extend_memory_pipeline.txt"}
+
+
 def build_workload(args):
     if args.scene:
         # a baked scene (e.g. Khronos Sponza prepared elsewhere); its own first camera is used
@@ -257,6 +285,9 @@ def main():
                 "launches": ext["launches"],
                 "avg_launch_ms": round(avg_ms, 5),
                 "algorithmic_bytes_per_launch": round(ext_bytes / launches, 1),
+                # what the kernel is measured to be limited by: the CU's vector-memory front end,
+                # not HBM (the algorithmic bytes are served by L1, L2 and the Infinity Cache)
+                "measured_limiter": profiled_extend_units() if default_run else None,
             },
             "counters_per_ray": {k: round(counters[k] / max(rays_local, 1), 3)
                                  for k in ("prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests")},
