@@ -654,11 +654,15 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                         const float b[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
                         cm |= (overlaps_world_box(oi, idir, b) ? 1ull : 0ull) << ch;
                     }
-                    if (nc < 64u) cm |= ~0ull << nc; // never 0: the chunks that do not exist end the walk
+                    if (nc < 64u) cm |= ~0ull << nc; // the chunks that do not exist end the walk
                     if (fresh && st == ST_SCAN) {
                         cmask = cm;
-                        cb = ((uint32_t)__builtin_ctzll(cm) << sc.chunk_shift) * 128u;
-                        if (cb >= sc.n_prims) retire();
+                        if (cm == 0ull) { // 64 super-chunks and the ray meets none of them
+                            retire();
+                        } else {
+                            cb = ((uint32_t)__builtin_ctzll(cm) << sc.chunk_shift) * 128u;
+                            if (cb >= sc.n_prims) retire();
+                        }
                     }
                 }
             }

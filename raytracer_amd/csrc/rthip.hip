@@ -90,10 +90,18 @@ struct rthip_ctx {
     float*    tap_t = nullptr;
     uint32_t* tap_seed = nullptr;
     bool      taps_valid = false;
-    uint64_t  buf_pixels = 0;
+    uint32_t  buf_res_x = 0, buf_res_y = 0; // resolution the work buffers are sized for
+    uint64_t  accum_own_pixels = 0;
     uint64_t  queue_cap = 0;
 
     unsigned long long* d_counters = nullptr;
+
+    // grow-only staging of rthip_trace_rays and rthip_resolve
+    float4*   tr_q = nullptr;
+    float4*   tr_hits = nullptr;
+    uint64_t  tr_cap = 0;
+    uint32_t* resolve_out = nullptr;
+    uint64_t  resolve_cap = 0;
 
     std::vector<EventPair>  pending_events;
     std::vector<hipEvent_t> free_events;
@@ -143,13 +151,22 @@ void free_scene(rthip_ctx* c) {
     c->have_scene = false;
 }
 
-void free_frame_buffers(rthip_ctx* c) {
-    free_dev_t(c->accum_own); free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
+// the per-frame work buffers: everything sized by the 8x8-tile slot count or the frame group
+void free_work_buffers(rthip_ctx* c) {
+    free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
     c->shadow_cap = 0;
     c->spill_words = 0;
     c->frames_cap = 0;
+    c->queue_cap = 0;
     free_dev_t(c->tap_tri); free_dev_t(c->tap_prim); free_dev_t(c->tap_t); free_dev_t(c->tap_seed);
-    c->buf_pixels = 0;
+    c->taps_valid = false;
+    c->buf_res_x = c->buf_res_y = 0;
+}
+
+void free_frame_buffers(rthip_ctx* c) {
+    free_work_buffers(c);
+    free_dev_t(c->accum_own);
+    c->accum_own_pixels = 0;
     if (!c->accum_is_bound) c->accum = nullptr;
 }
 
@@ -203,39 +220,50 @@ uint32_t frames_in_flight_limit(const rthip_ctx* c) {
     return want;
 }
 
+// Queue slots are handed out per 8x8 pixel tile, so the work buffers are keyed on the resolution
+// itself: two resolutions of equal pixel count can differ in tiles (1000x500 has 7875, 2000x250 has
+// 8000).  The library-owned accumulator is keyed on the pixel count and survives a re-allocation
+// of the work buffers (a larger frame group must not lose the image).
 int ensure_frame_buffers(rthip_ctx* c, uint32_t frames) {
     const uint64_t n = c->n_pixels;
-    if (c->buf_pixels == n && c->queue_mem && c->frames_cap >= frames) return RTHIP_OK;
-    const bool keep_accum = c->buf_pixels == n && c->accum_own != nullptr;
-    float4* kept = nullptr;
-    if (keep_accum) { kept = c->accum_own; c->accum_own = nullptr; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_frame_buffers(c);
-    // queue slots are handed out per 8x8 pixel tile, so edge tiles pad the capacity
-    const uint64_t per_frame = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
-    const uint64_t cap = per_frame * frames;
-    c->queue_cap = cap;
-    HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * cap));
-    HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * cap));
-    HIP_TRY(c, hipMalloc((void**)&c->partial, sizeof(float4) * n * frames));
-    HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
-    HIP_TRY(c, hipMalloc((void**)&c->tap_prim, sizeof(int32_t) * n));
-    HIP_TRY(c, hipMalloc((void**)&c->tap_t, sizeof(float) * n));
-    HIP_TRY(c, hipMalloc((void**)&c->tap_seed, sizeof(uint32_t) * n));
-    c->taps_valid = false;
-    if (!c->accum_is_bound) {
-        if (kept) {
-            c->accum_own = kept;
-        } else {
+    const bool same_res = c->buf_res_x == c->res_x && c->buf_res_y == c->res_y;
+    if (!(same_res && c->queue_mem && c->frames_cap >= frames)) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_work_buffers(c);
+        const uint64_t per_frame = (uint64_t)((c->res_x + 7) / 8) * ((c->res_y + 7) / 8) * 64;
+        const uint64_t cap = per_frame * frames;
+        HIP_TRY(c, hipMalloc((void**)&c->queue_mem, sizeof(float4) * 8 * cap));
+        HIP_TRY(c, hipMalloc((void**)&c->hits, sizeof(float4) * cap));
+        HIP_TRY(c, hipMalloc((void**)&c->partial, sizeof(float4) * n * frames));
+        HIP_TRY(c, hipMalloc((void**)&c->tap_tri, sizeof(int32_t) * n));
+        HIP_TRY(c, hipMalloc((void**)&c->tap_prim, sizeof(int32_t) * n));
+        HIP_TRY(c, hipMalloc((void**)&c->tap_t, sizeof(float) * n));
+        HIP_TRY(c, hipMalloc((void**)&c->tap_seed, sizeof(uint32_t) * n));
+        // only now do the sizes count: a failure above leaves frames_cap = 0 and the next call retries
+        c->queue_cap = cap;
+        c->frames_cap = frames;
+        c->buf_res_x = c->res_x;
+        c->buf_res_y = c->res_y;
+    }
+    if (c->accum_is_bound) {
+        if (c->accum_own) { // not in use while a caller's buffer is bound
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            free_dev_t(c->accum_own);
+            c->accum_own_pixels = 0;
+        }
+    } else {
+        if (c->accum_own && c->accum_own_pixels != n) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            free_dev_t(c->accum_own);
+            c->accum_own_pixels = 0;
+        }
+        if (!c->accum_own) {
             HIP_TRY(c, hipMalloc((void**)&c->accum_own, sizeof(float4) * n));
+            c->accum_own_pixels = n;
             HIP_TRY(c, hipMemsetAsync(c->accum_own, 0, sizeof(float4) * n, c->stream));
         }
         c->accum = c->accum_own;
-    } else if (kept) {
-        (void)hipFree(kept);
     }
-    c->buf_pixels = n;
-    c->frames_cap = frames;
     return RTHIP_OK;
 }
 
@@ -356,6 +384,7 @@ void rthip_destroy(rthip_ctx* c) {
     free_frame_buffers(c);
     free_dev_t(c->ctrl);
     free_dev_t(c->d_counters);
+    free_dev_t(c->tr_q); free_dev_t(c->tr_hits); free_dev_t(c->resolve_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -711,10 +740,19 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     uint32_t prim_count;
     std::memcpy(&prim_count, c->uniforms + 600, 4);
     if (prim_count != c->sc.n_prims) return fail(c, RTHIP_ERR_INVALID, "render: uniforms say %u primitives, scene has %u", prim_count, c->sc.n_prims);
-    if (n_frames == 0) return RTHIP_OK;
     (void)hipGetLastError(); // an error left behind by other code of the process is not this call's
 
     DeviceGuard g(c->device);
+    if (n_frames == 0) {
+        // No sample, but the reject_hist protocol still holds: an accumulator that was to be
+        // overwritten by the first frame now holds zero samples (a GPU of a group that gets no
+        // frame of a short render must not discard, later, what a reduce left in its buffer).
+        if (c->reject_hist == 1 && c->accum && (c->accum_is_bound || c->accum_own_pixels == c->n_pixels)) {
+            HIP_TRY(c, hipMemsetAsync(c->accum, 0, sizeof(float4) * c->n_pixels, c->stream));
+            c->reject_hist = 0;
+        }
+        return RTHIP_OK;
+    }
     const uint32_t group = std::min<uint32_t>(n_frames, frames_in_flight_limit(c));
     int rc = ensure_frame_buffers(c, group);
     if (rc != RTHIP_OK) return rc;
@@ -932,17 +970,24 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
         std::memcpy(&s1[2], &seed, 4);
         std::memcpy(&s1[3], &slot, 4);
     }
-    float4* d_q = nullptr;
-    float4* d_hits = nullptr;
-    uint32_t* d_ctl = nullptr; // [0] = ray count, [1] = cursor
-    auto cleanup = [&]() { free_dev_t(d_q); free_dev_t(d_hits); free_dev_t(d_ctl); };
-    hipError_t e = hipMalloc((void**)&d_q, sizeof(float4) * 2 * n);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_hits, sizeof(float4) * n);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_ctl, sizeof(uint32_t) * 2);
+    // staging grows to the largest query seen and is kept (no allocation per call)
+    hipError_t e = hipSuccess;
+    if (c->tr_cap < n) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_dev_t(c->tr_q); free_dev_t(c->tr_hits);
+        c->tr_cap = 0;
+        e = hipMalloc((void**)&c->tr_q, sizeof(float4) * 2 * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&c->tr_hits, sizeof(float4) * n);
+        if (e != hipSuccess) { free_dev_t(c->tr_q); free_dev_t(c->tr_hits); return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e)); }
+        c->tr_cap = n;
+    }
+    float4* const d_q = c->tr_q;
+    float4* const d_hits = c->tr_hits;
+    uint32_t* const d_ctl = c->ctrl + 192; // [0] = ray count, [1] = cursor (words no render uses)
     const uint32_t ctl[2] = {(uint32_t)n, 0u};
     if (e == hipSuccess) e = hipMemcpyAsync(d_q, planes.data(), sizeof(float4) * 2 * n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { cleanup(); return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
 
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
     const bool multi = c->sc.n_chunks > 1u;
@@ -958,7 +1003,7 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
             free_dev_t(c->spill);
             c->spill_words = 0;
             e = hipMalloc((void**)&c->spill, sizeof(uint32_t) * words);
-            if (e != hipSuccess) { cleanup(); return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
             c->spill_words = words;
         }
     }
@@ -988,7 +1033,6 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(hits.data(), d_hits, sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
     for (uint64_t i = 0; i < n; i++) {
         const float* h = &hits[(size_t)i * 4];
@@ -1014,7 +1058,6 @@ int rthip_bind_accum(rthip_ctx* c, void* device_ptr, uint64_t n_pixels) {
         c->accum_is_bound = false;
         c->accum_bound_pixels = 0;
         c->accum = c->accum_own;
-        c->buf_pixels = 0; // forces re-allocation of an owned accumulator on the next render
         c->reject_hist = 1;
         return RTHIP_OK;
     }
@@ -1114,13 +1157,18 @@ int rthip_resolve(rthip_ctx* c, uint8_t* rgba8, uint64_t n_pixels, int apply_srg
     if (!rgba8) return fail(c, RTHIP_ERR_INVALID, "resolve: null output");
     if (!c->accum || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "resolve: size mismatch");
     DeviceGuard g(c->device);
-    uint32_t* d_out = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_out, 4 * n_pixels));
+    if (c->resolve_cap < n_pixels) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_dev_t(c->resolve_out);
+        c->resolve_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->resolve_out, 4 * n_pixels));
+        c->resolve_cap = n_pixels;
+    }
+    uint32_t* const d_out = c->resolve_out;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n_pixels + 255) / 256);
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, c->stream, (const float4*)c->accum, d_out, n_pixels, apply_srgb_oetf);
     hipError_t e = hipMemcpyAsync(rgba8, d_out, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "resolve: %s", hipGetErrorString(e));
     return RTHIP_OK;
 }

@@ -20,6 +20,7 @@ struct rthip_group {
     std::vector<float*>       accum;     // group-owned accumulators, bound to the contexts
     std::vector<ncclComm_t>   comm;      // empty until the first reduce
     uint64_t                  n_pixels = 0;
+    uint32_t                  res_x = 0, res_y = 0;
     std::string               error;
 };
 
@@ -145,9 +146,11 @@ int rthip_group_set_frame_uniforms(rthip_group* g, const void* blob608) {
     std::memcpy(&reject, static_cast<const uint8_t*>(blob608) + 592, 4); // FrameUniforms.reject_hist
     const uint64_t np = (uint64_t)res[0] * res[1];
     if (np == 0 || np >= 0x7FFFFFFFull) return fail(g, RTHIP_ERR_INVALID, "set_frame_uniforms: resolution %ux%u", res[0], res[1]);
-    const bool resized = np != g->n_pixels;
+    // a change of shape at equal pixel count (WxH -> HxW) is a new image too
+    const bool resized = res[0] != g->res_x || res[1] != g->res_y;
+    const bool realloc = np != g->n_pixels;
     const int n = (int)g->ctx.size();
-    if (resized) {
+    if (realloc) {
         // update_resolution (main.rs:79-94): a new accumulator, owned here so that it exists
         // (zeroed) on a GPU that gets no frame before a reduce.  A context accepts a new
         // resolution only while no accumulator of another size is bound to it.
@@ -165,7 +168,7 @@ int rthip_group_set_frame_uniforms(rthip_group* g, const void* blob608) {
     int rc = for_each_rank(g, "set_frame_uniforms", [&](int r) { return rthip_set_frame_uniforms(g->ctx[r], blob608); });
     if (rc != RTHIP_OK) return rc;
     for (int r = 0; r < n; r++) {
-        if (resized) {
+        if (realloc) {
             rc = rthip_bind_accum(g->ctx[r], g->accum[r], np);
             if (rc != RTHIP_OK) return fail(g, rc, "set_frame_uniforms: rank %d: %s", r, rthip_last_error(g->ctx[r]));
         }
@@ -176,6 +179,8 @@ int rthip_group_set_frame_uniforms(rthip_group* g, const void* blob608) {
         }
     }
     g->n_pixels = np;
+    g->res_x = res[0];
+    g->res_y = res[1];
     return RTHIP_OK;
 }
 
@@ -196,7 +201,8 @@ int rthip_group_render(rthip_group* g, uint32_t first_frame, uint32_t n_frames, 
     return for_each_rank(g, "render", [&](int r) {
         uint32_t first, count;
         rthip_group_plan(first_frame, n_frames, n, r, &first, &count);
-        if (count == 0) return (int)RTHIP_OK;
+        // a GPU without a frame still takes part: a render of zero frames settles its reject_hist
+        // state, so that it does not overwrite, later, a sum that a reduce left in its accumulator
         return rthip_render(g->ctx[r], first, count, (uint32_t)n, params);
     });
 }

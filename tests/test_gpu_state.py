@@ -1,0 +1,122 @@
+"""State handling of a device context across calls: buffers that follow the resolution, the
+reject_hist protocol when a call renders nothing, and the candidate scan at its 64-bit edge."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import device, procedural
+from util import oracle_params, oracle_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def fresh(scene, arrays, res, first, n, params=None):
+    c = device.Context(0)
+    try:
+        c.upload_scene(arrays)
+        c.set_frame_uniforms(scene.frame_uniforms(res, frame=first, reject_hist=1))
+        c.render(first, n, 1, params or device.default_params())
+        return c.read_accum()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("a_res,b_res", [((8, 5), (40, 1)), ((1000, 500), (2000, 250)), ((96, 64), (64, 96))])
+def test_resolution_change_at_equal_pixel_count(a_res, b_res):
+    """Queue slots go by 8x8 tile: 8x5 has one tile, 40x1 five; 1000x500 has 7875, 2000x250 has
+    8000.  A context that rendered the first shape must size its queues again for the second."""
+    s = procedural.box_scene(env_size=(64, 32))
+    a = s.arrays()
+    assert a_res[0] * a_res[1] == b_res[0] * b_res[1]
+    c = device.Context(0)
+    try:
+        c.upload_scene(a)
+        for res in (a_res, b_res, a_res):
+            c.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=0))  # the change of shape itself resets
+            c.render(1, 3, 1, device.default_params())
+            got = c.read_accum()
+            assert got.shape == (res[1], res[0], 4)
+            assert np.array_equal(got, fresh(s, a, res, 1, 3)), res
+    finally:
+        c.close()
+
+
+def test_larger_frame_group_keeps_the_image():
+    """Growing the work buffers (a later call with more frames in flight) must not lose what the
+    library-owned accumulator already holds."""
+    s = procedural.box_scene(env_size=(64, 32))
+    a = s.arrays()
+    res = (64, 48)
+    c = device.Context(0)
+    try:
+        c.upload_scene(a)
+        c.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+        c.render(1, 2, 1, device.default_params())
+        c.render(3, 9, 1, device.default_params())
+        assert np.array_equal(c.read_accum(), fresh(s, a, res, 1, 11))
+    finally:
+        c.close()
+
+
+def test_render_of_zero_frames_settles_reject_hist():
+    """A GPU of a group that gets no frame of a short render: its accumulator holds zero samples
+    afterwards, and a sum that a reduce then leaves there is added to, not overwritten."""
+    import torch
+    s = procedural.box_scene(env_size=(64, 32))
+    a = s.arrays()
+    res = (48, 32)
+    n = res[0] * res[1]
+    one = fresh(s, a, res, 7, 1)
+    c = device.Context(0)
+    try:
+        acc = torch.full((n * 4,), 3.0, dtype=torch.float32, device="cuda:0")
+        c.upload_scene(a)
+        c.bind_accum(acc.data_ptr(), n)
+        c.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+        c.render(1, 0, 2, device.default_params())
+        c.synchronize()
+        assert not acc.cpu().numpy().any()
+        acc.fill_(5.0)  # what a reduce to this GPU would have left
+        torch.cuda.synchronize()
+        c.set_frame_uniforms(s.frame_uniforms(res, frame=7, reject_hist=0))
+        c.render(7, 1, 1, device.default_params())
+        c.synchronize()
+        got = acc.cpu().numpy().reshape(res[1], res[0], 4)
+        assert np.array_equal(got, one + np.float32(5.0))
+        c.bind_accum(0, 0)
+    finally:
+        c.close()
+
+
+def test_sixty_four_super_chunks_and_rays_that_meet_none():
+    """8192 instanced primitives = 64 chunks of 128 = 64 super-chunks: every bit of a ray's chunk
+    mask names a real chunk, so a ray that meets none has an empty mask."""
+    s = procedural.terrain_scene(tiles=64, n=8, env_size=(64, 32), instanced=True)
+    a = s.arrays()
+    assert a["prims"].shape[0] == 8192
+    c = device.Context(0)
+    try:
+        c.upload_scene(a)
+        sc = oracle_scene(a)
+        rng = np.random.default_rng(5)
+        n = 256
+        o = np.column_stack([rng.uniform(-1200, 1200, n), rng.uniform(-1200, 1200, n), rng.uniform(0.5, 40, n)]).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[:, 2] -= 0.3
+        # a quarter of the rays start far above everything and point up: they meet no bound at all
+        o[::4, 2] = 5000.0
+        d[::4, 2] = np.abs(d[::4, 2]) + 0.5
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        q = c.trace_rays(o, d)
+        op = oracle_params(device.default_params())
+        hits = 0
+        for i in range(n):
+            tri, prim, t, _ = orc.trace_ray(sc, o[i], d[i], op, 0)
+            assert q["tri"][i] == tri, i
+            if tri >= 0:
+                hits += 1
+                assert q["prim"][i] == prim and q["t"][i] == np.float32(t), i
+        assert np.all(q["tri"][::4] == -1) and np.all(q["t"][::4] == np.float32(99999999.0))
+        assert hits > n // 8
+    finally:
+        c.close()
