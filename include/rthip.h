@@ -180,6 +180,22 @@ int rthip_trace_rays(rthip_ctx* ctx, const float* rays6, uint32_t* seeds, uint64
                      const rthip_render_params* params, float* t, int32_t* tri_idx,
                      int32_t* prim_idx, uint8_t* overflow);
 
+/* rthip_trace_rays for callers that cannot allocate.  No counterpart in the reference: it is for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Calls no
+ * hipMalloc / hipFree (nor any allocating library routine): the kernels' work memory (queue
+ * planes, hit records, control words, deep traversal-stack columns) is a fixed array in the
+ * library's device image, about 19 MB that every GPU the library runs on holds until the process
+ * ends.  At most RTHIP_NOALLOC_MAX_RAYS rays per call; more is RTHIP_ERR_INVALID.
+ * ALL pointers are DEVICE memory of the context's GPU (caller-owned): d_rays6 as rays6 above,
+ * d_seeds (may be NULL) read and advanced in place, outputs as above (any may be NULL).
+ * Asynchronous: the work is enqueued on the context's stream and nothing is synchronised.
+ * Every call on a GPU, from any context, uses that GPU's one array: calls that overlap in time on
+ * one GPU (two contexts, two streams) race; calls on one stream are ordered and safe. */
+#define RTHIP_NOALLOC_MAX_RAYS (1u << 18)
+int rthip_trace_rays_noalloc(rthip_ctx* ctx, const float* d_rays6, uint32_t* d_seeds, uint64_t n,
+                             const rthip_render_params* params, float* d_t, int32_t* d_tri_idx,
+                             int32_t* d_prim_idx, uint8_t* d_overflow);
+
 /* The render pass of frame() (main.rs:395-401; fs_main, shader.wgsl:994-1012): mean, PBR
  * Neutral tonemap, then the linear->sRGB transfer the reference gets from its sRGB surface
  * (main.rs:116) when apply_srgb_oetf != 0, rounded to 8 bits; alpha = 255. */

@@ -1290,3 +1290,31 @@ __global__ __launch_bounds__(256) void k_resolve(const float4* accum, uint32_t* 
         rgba8[i] = to_unorm8(col.x, srgb != 0) | (to_unorm8(col.y, srgb != 0) << 8) | (to_unorm8(col.z, srgb != 0) << 16) | 0xFF000000u;
     }
 }
+
+// ------------------------------------------------------------------ ray queries on device buffers
+
+// Caller rays (origin.xyz, direction.xyz per ray) and RNG states as the first two planes of a
+// path queue, and the queue's control words: ctl[0] = number of rays, ctl[1] = the extend
+// stage's cursor, which must start at zero.
+__global__ __launch_bounds__(256) void k_pack_rays(const float* rays6, const uint32_t* seeds, uint32_t n, float4* s0, float4* s1, uint32_t* ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0u) { ctl[0] = n; ctl[1] = 0u; }
+    if (i >= n) return;
+    const float* r = rays6 + (size_t)i * 6u;
+    s0[i] = make_float4(r[0], r[1], r[2], r[3]);
+    s1[i] = make_float4(r[4], r[5], __uint_as_float(seeds ? seeds[i] : 0u), __uint_as_float(0u));
+}
+
+// Hit records (t, triangle, primitive | overflow << 31, seed) as the separate arrays of the C ABI.
+__global__ __launch_bounds__(256) void k_unpack_hits(const float4* hits, uint32_t n, float* t, int32_t* tri_idx, int32_t* prim_idx, uint8_t* overflow, uint32_t* seeds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = hits[i];
+    const int32_t tri = __float_as_int(h.y);
+    const uint32_t primw = __float_as_uint(h.z);
+    if (t) t[i] = h.x;
+    if (tri_idx) tri_idx[i] = tri;
+    if (prim_idx) prim_idx[i] = tri >= 0 ? (int32_t)(primw & 0x7FFFFFFFu) : -1;
+    if (overflow) overflow[i] = (uint8_t)(primw >> 31);
+    if (seeds) seeds[i] = __float_as_uint(h.w);
+}

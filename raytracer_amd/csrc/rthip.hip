@@ -15,6 +15,20 @@
 #include <string>
 #include <vector>
 
+// Work memory of rthip_trace_rays_noalloc, the entry point that may not allocate: the queue
+// planes, hit records and control words its kernels use, and the deep part of the traversal
+// stacks.  One copy per GPU, held until the process ends; its device address is looked up once
+// per context (hipGetSymbolAddress) -- the name below is only the host-side handle of the symbol.
+#define RT_NOALLOC_MAX_RAYS   RTHIP_NOALLOC_MAX_RAYS
+#define RT_NOALLOC_DEEP_GRID  128u   // blocks of 256 threads the extend stage gets when it needs deep stacks
+#define RT_NOALLOC_CTL_BYTES  256u
+#define RT_NOALLOC_PLANES_OFF ((size_t)RT_NOALLOC_CTL_BYTES)
+#define RT_NOALLOC_HITS_OFF   (RT_NOALLOC_PLANES_OFF + (size_t)32 * RT_NOALLOC_MAX_RAYS)
+#define RT_NOALLOC_SPILL_OFF  (RT_NOALLOC_HITS_OFF + (size_t)16 * RT_NOALLOC_MAX_RAYS)
+#define RT_NOALLOC_SPILL_WORDS ((size_t)(RT_MAX_STACK - RT_LDS_LEVELS_SINGLE) * RT_NOALLOC_DEEP_GRID * 256u)
+#define RT_NOALLOC_BYTES      (RT_NOALLOC_SPILL_OFF + 4 * RT_NOALLOC_SPILL_WORDS)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+
 namespace {
 
 thread_local std::string g_global_error;
@@ -96,6 +110,7 @@ struct rthip_ctx {
 
     unsigned long long* d_counters = nullptr;
 
+    unsigned char* noalloc_scratch = nullptr; // this device's copy of `scratch` (rthip_trace_rays_noalloc)
     // grow-only staging of rthip_trace_rays and rthip_resolve
     float4*   tr_q = nullptr;
     float4*   tr_hits = nullptr;
@@ -370,6 +385,9 @@ int rthip_create(int device_ordinal, rthip_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(Counters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(Counters));
     if (e != hipSuccess) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    // every GPU holds its own copy of the static work array at its own address
+    e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !c->noalloc_scratch) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
     *out = c;
     return RTHIP_OK;
 }
@@ -1047,6 +1065,66 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
         if (overflow) overflow[i] = (uint8_t)(primw >> 31);
         if (seeds) seeds[i] = seed;
     }
+    return RTHIP_OK;
+}
+
+int rthip_trace_rays_noalloc(rthip_ctx* c, const float* d_rays6, uint32_t* d_seeds, uint64_t n, const rthip_render_params* params,
+                             float* d_t, int32_t* d_tri_idx, int32_t* d_prim_idx, uint8_t* d_overflow) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "trace_rays_noalloc: no scene uploaded");
+    if (n == 0) return RTHIP_OK;
+    if (!d_rays6) return fail(c, RTHIP_ERR_INVALID, "trace_rays_noalloc: null rays");
+    if (n > RT_NOALLOC_MAX_RAYS)
+        return fail(c, RTHIP_ERR_INVALID, "trace_rays_noalloc: %llu rays exceed the fixed work memory of %u rays per call (split the query, or use rthip_trace_rays)",
+                    (unsigned long long)n, RT_NOALLOC_MAX_RAYS);
+    rthip_render_params P;
+    if (params) P = *params; else rthip_default_params(&P);
+    if (P.stack_depth == 0 || P.stack_depth > RTHIP_MAX_STACK_DEPTH) return fail(c, RTHIP_ERR_INVALID, "trace_rays_noalloc: stack_depth %u outside 1..%u", P.stack_depth, RTHIP_MAX_STACK_DEPTH);
+    DeviceGuard g(c->device);
+
+    // the pieces of this device's static work array (addresses from hipGetSymbolAddress)
+    unsigned char* const w = c->noalloc_scratch;
+    uint32_t* const ctl = reinterpret_cast<uint32_t*>(w);
+    float4* const planes = reinterpret_cast<float4*>(w + RT_NOALLOC_PLANES_OFF);
+    float4* const hits = reinterpret_cast<float4*>(w + RT_NOALLOC_HITS_OFF);
+    uint32_t* const spill = reinterpret_cast<uint32_t*>(w + RT_NOALLOC_SPILL_OFF);
+
+    const uint32_t nn = (uint32_t)n;
+    const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
+    const bool multi = c->sc.n_chunks > 1u;
+    const bool deep = P.stack_depth > rt_lds_levels(multi);
+    const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
+    const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
+    const int blocks = extend_occupancy(count, deep, multi);
+    uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * blocks, (n + 255) / 256);
+    if (deep) grid = std::min<uint32_t>(grid, RT_NOALLOC_DEEP_GRID); // the deep stack columns are a fixed part of the work array
+    (void)hipGetLastError(); // not this call's
+
+    const uint32_t flat_grid = (nn + 255u) / 256u;
+    hipLaunchKernelGGL(k_pack_rays, dim3(flat_grid), dim3(256), 0, c->stream, d_rays6, (const uint32_t*)d_seeds, nn, planes, planes + RT_NOALLOC_MAX_RAYS, ctl);
+    ExtArgs ea{};
+    ea.sc = c->sc;
+    ea.in.s0 = planes; ea.in.s1 = planes + RT_NOALLOC_MAX_RAYS; ea.in.s2 = planes; ea.in.s3 = planes;
+    ea.hits = hits;
+    ea.spill = spill;
+    ea.count_in = ctl;
+    ea.cursor = ctl + 1;
+    ea.stack_depth = P.stack_depth;
+    ea.counters = c->d_counters;
+    ea.nan_inner = nanw.inner; ea.nan_leaf = nanw.leaf; ea.nan_tri = nanw.tri; ea.nan_dropped = nanw.dropped;
+    ea.nan_overflow = nanw.dropped ? 1u : 0u;
+    ea.no_cull = cull ? 0u : 1u;
+    if (cull) {
+        CullArgs ca{};
+        ca.sc = c->sc;
+        ca.in = ea.in;
+        ca.masks = reinterpret_cast<uint4*>(hits);
+        ca.count_in = ctl;
+        hipLaunchKernelGGL(k_cull, dim3(std::min<uint32_t>((uint32_t)c->n_cu * 8u, flat_grid)), dim3(256), 0, c->stream, ca);
+    }
+    extend_launch(count, deep, multi, grid, c->stream, ea);
+    hipLaunchKernelGGL(k_unpack_hits, dim3(flat_grid), dim3(256), 0, c->stream, (const float4*)hits, nn, d_t, d_tri_idx, d_prim_idx, d_overflow, d_seeds);
+    HIP_TRY(c, hipGetLastError());
     return RTHIP_OK;
 }
 

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
 FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
+NOALLOC_MAX_RAYS = 1 << 18
 STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "shadow", "cull")
 
 EXPORTS = (
@@ -24,7 +25,7 @@ EXPORTS = (
     "rthip_read_taps", "rthip_read_nodes_device_layout", "rthip_read_node_index_map",
     "rthip_read_tri_order", "rthip_read_tris_device_layout", "rthip_resolve",
     "rthip_get_counters", "rthip_reset_counters", "rthip_get_timing", "rthip_reset_timing",
-    "rthip_synchronize", "rthip_copy_bandwidth", "rthip_trace_rays",
+    "rthip_synchronize", "rthip_copy_bandwidth", "rthip_trace_rays", "rthip_trace_rays_noalloc",
 )
 
 
@@ -88,6 +89,7 @@ def lib():
         l.rthip_default_params.argtypes = [C.POINTER(RenderParams)]
         l.rthip_reserve.argtypes = [vp, C.c_uint32]
         l.rthip_trace_rays.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
+        l.rthip_trace_rays_noalloc.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_copy_bandwidth.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
         l.rthip_default_params.restype = None
         l.rthip_render.argtypes = [vp, u32, u32, u32, C.POINTER(RenderParams)]
@@ -204,6 +206,15 @@ class Context:
         p = params or default_params()
         self._check(lib().rthip_trace_rays(self._h, _p(rays), _p(sd), n, C.byref(p), _p(t), _p(tri), _p(prim), _p(ovf)))
         return dict(t=t, tri=tri, prim=prim, overflow=ovf, seed=sd)
+
+    def trace_rays_noalloc(self, d_rays6, d_seeds, n, d_t, d_tri, d_prim, d_overflow, params=None):
+        """rthip_trace_rays_noalloc: every argument but n and params is a DEVICE address (int, 0 =
+        NULL) of caller-owned memory on this context's GPU; asynchronous on the context's stream;
+        at most NOALLOC_MAX_RAYS rays."""
+        p = params or default_params()
+        v = lambda x: C.c_void_p(x) if x else None  # noqa: E731
+        self._check(lib().rthip_trace_rays_noalloc(self._h, v(d_rays6), v(d_seeds), int(n), C.byref(p),
+                                                   v(d_t), v(d_tri), v(d_prim), v(d_overflow)))
 
     def reserve(self, n_frames):
         """Allocate the work buffers for calls of up to n_frames frames ahead of the first render."""

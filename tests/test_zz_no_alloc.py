@@ -1,0 +1,81 @@
+"""rthip_trace_rays_noalloc (the entry point that allocates nothing) against rthip_trace_rays,
+through the C ABI: bit-identical outputs on two calls in a row, the second with fewer rays, on a
+scene whose BLEND materials advance the seeds, with the default and with a deep traversal stack."""
+import numpy as np
+import pytest
+
+from raytracer_amd import device, procedural
+
+pytestmark = pytest.mark.gpu
+
+
+def rays_for(scene_arrays, n, seed):
+    rng = np.random.default_rng(seed)
+    v = scene_arrays["tris"]["v"][:, :, :3].reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    c, e = (lo + hi) / 2, (hi - lo)
+    o = (c + rng.uniform(-0.8, 0.8, (n, 3)) * e).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    seeds = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    return o, d, seeds
+
+
+def noalloc(ctx, torch, o, d, seeds, params):
+    n = o.shape[0]
+    dev = "cuda:0"
+    rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([o, d], axis=1))).to(dev)
+    sd = torch.from_numpy(seeds.view(np.int32).copy()).to(dev)
+    t = torch.full((n,), -7.0, dtype=torch.float32, device=dev)
+    tri = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    prim = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    ovf = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.trace_rays_noalloc(rays.data_ptr(), sd.data_ptr(), n, t.data_ptr(), tri.data_ptr(), prim.data_ptr(), ovf.data_ptr(), params)
+    ctx.synchronize()
+    return dict(t=t.cpu().numpy(), tri=tri.cpu().numpy(), prim=prim.cpu().numpy(), overflow=ovf.cpu().numpy(),
+                seed=sd.cpu().numpy().view(np.uint32))
+
+
+def compare(ctx, torch, arrays, n, seed, params):
+    o, d, seeds = rays_for(arrays, n, seed)
+    ref = ctx.trace_rays(o, d, seeds, params)
+    got = noalloc(ctx, torch, o, d, seeds, params)
+    for k in ("tri", "prim", "overflow", "seed"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert got["t"].tobytes() == ref["t"].tobytes()
+    return ref
+
+
+@pytest.mark.parametrize("scene_name", ["materials", "terrain_deep", "instanced"])
+def test_noalloc_equals_trace_rays_twice_in_a_row(scene_name):
+    import torch
+    if scene_name == "materials":
+        s, params, sizes = procedural.material_test_scene(tex=32, env_size=(64, 32)), device.default_params(), (70001, 3000)
+    elif scene_name == "terrain_deep":  # stack_depth above the LDS levels: the deep columns of the work array
+        s, params, sizes = procedural.terrain_scene(tiles=6, env_size=(64, 32)), device.default_params(stack_depth=40), (50000, 777)
+    else:                               # more than 128 primitives: the in-kernel candidate scan
+        s, params, sizes = procedural.terrain_scene(tiles=10, n=12, env_size=(64, 32), instanced=True), device.default_params(), (device.NOALLOC_MAX_RAYS, 64)
+    a = s.arrays()
+    ctx = device.Context(0)
+    try:
+        ctx.upload_scene(a)
+        first = compare(ctx, torch, a, sizes[0], 1, params)
+        second = compare(ctx, torch, a, sizes[1], 2, params)   # fewer rays: the work array still holds the first call's
+        assert (first["tri"] >= 0).any() and (second["tri"] >= 0).any()
+        if scene_name == "materials":
+            sd = rays_for(a, sizes[0], 1)[2]
+            assert (first["seed"] != sd).any()                  # BLEND alpha tests drew from the seeds
+    finally:
+        ctx.close()
+
+
+def test_noalloc_rejects_more_rays_than_its_work_array_holds():
+    s = procedural.box_scene(env_size=(64, 32))
+    ctx = device.Context(0)
+    try:
+        ctx.upload_scene(s.arrays())
+        with pytest.raises(device.RtHipError, match="exceed the fixed work memory"):
+            ctx.trace_rays_noalloc(16, 0, device.NOALLOC_MAX_RAYS + 1, 0, 0, 0, 0)
+    finally:
+        ctx.close()
