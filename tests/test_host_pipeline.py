@@ -1,5 +1,7 @@
 """The host-side scene pipeline (librthost.so) against the oracle's restatement of scene.rs and
 against closed forms: BVH builder bit-exactness, record packing, cameras, frame uniforms."""
+import os
+
 import numpy as np
 import pytest
 
@@ -228,3 +230,43 @@ def test_scene_cache_round_trip(tmp_path):
     open(path, "wb").write(bad)
     with pytest.raises(host.RtHostError):
         host.Scene.from_cache(path)
+
+
+def test_baked_reference_fixtures_load_and_match_the_mounted_assets(reference_resources):
+    """tests/golden/ref_*.rtscene.gz are what this build's host pipeline makes of the reference's
+    bundled scenes (tools/bake_reference_assets.py); with the reference mounted, loading the
+    assets again gives the same bytes, and trail.hdr decodes to the floats the RGBE fixture gives."""
+    from util import REFERENCE_SCENES, load_reference_scene, reference_env
+    names = {"box": "Box.gltf", "suzanne": "suzanne.glb", "simple_terrain": "simple_terrain.glb",
+             "simple_with_camera": "simple_with_camera.glb"}
+    assert set(names) == set(REFERENCE_SCENES)
+    for key, fname in names.items():
+        baked, a = load_reference_scene(key, env=False)
+        live = host.Scene.from_path(os.path.join(reference_resources, fname))
+        b = live.arrays()
+        for k in ("tris", "tri_exts", "nodes", "prims", "texels", "tri_order"):
+            assert a[k].tobytes() == b[k].tobytes(), (key, k)
+        assert baked.n_cameras == live.n_cameras == 1
+        assert bytes(baked.camera(0).c) == bytes(live.camera(0).c)
+    s = host.Scene()
+    s.set_equirectangular_env_map(os.path.join(reference_resources, "trail.hdr"))
+    assert np.array_equal(s.env_map_data.view(np.uint32), reference_env().view(np.uint32))
+
+
+def test_baked_reference_fixtures_are_self_consistent():
+    """Without the reference: the fixtures load, have the documented shapes, and the oracle still
+    reproduces the pinned primary hits of configuration 1 (Box.gltf, 512x512, frame 1)."""
+    from oracle import orc
+    from util import GOLDEN, load_reference_scene, oracle_scene
+    shapes = {"box": (12, 1), "suzanne": (15744, 1), "simple_terrain": (8198, 2), "simple_with_camera": (970, 2)}
+    for key, (n_tris, n_prims) in shapes.items():
+        s, a = load_reference_scene(key, env=False)
+        assert a["tris"].shape[0] == n_tris and a["prims"].shape[0] == n_prims and s.n_cameras == 1
+    s, a = load_reference_scene("box")
+    assert a["env"].shape == (512, 1024, 4)
+    u = s.frame_uniforms((512, 512), frame=1, reject_hist=1)
+    r = orc.render(oracle_scene(a), u, first_frame=1, n_frames=1, taps=True, n_threads=4)
+    pinned = np.load(os.path.join(GOLDEN, "ref_box_config1_taps.npz"))
+    assert np.array_equal(r["tri"], pinned["hit_tri"].astype(np.int32))
+    assert np.array_equal(r["prim"], pinned["hit_prim"].astype(np.int32))
+    assert r["counters"]["rays"] == int(pinned["rays"])
