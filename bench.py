@@ -3,26 +3,105 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one 1-spp frame (generate + max_bounces x (extend + shade)) of the 1920x1080
-workload; N > 1 is launched by torch.distributed.run with one rank per GPU, each rank rendering
-its own stripe of frame indices (rank r renders frames r+1, r+1+N, ...) into a private
+A step is one 1-spp frame (generate + max_bounces x (cull + extend + shade) + accumulate) of the
+1920x1080 workload.  N > 1 runs one rank per GPU (torch.distributed, RCCL): under
+torch.distributed.run the ranks are given; started plainly, this script starts them itself as a
+child launcher BEFORE touching any GPU, and refuses (exit status 2) when the node has fewer than N
+GPUs or the launcher's world size is not N -- it never reports N GPUs from fewer devices.  Each
+rank renders its own stripe of frame indices (rank r: frames r+1, r+1+N, ...) into a private
 accumulator that one RCCL sum-reduce to rank 0 merges at the end (inside the timed region).
+--spp-total S makes it a fixed job of S frames striped over the ranks (strong scaling).
+--one-process drives the N GPUs from this one process through librthip_group instead.
 Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from raytracer_amd import device, procedural  # noqa: E402
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, vendor figure
+L2_PEAK_GBS = 34500.0   # aggregate L2 -> L1 rate of the eight XCDs
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_per_ray.json")
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor figure
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--spp-total", type=int, default=0,
+                    help="strong scaling: a fixed job of this many frames striped over the GPUs (overrides --steps)")
+    ap.add_argument("--one-process", action="store_true", help="drive all GPUs from this process (librthip_group) instead of one rank per GPU")
+    ap.add_argument("--workload", default="atrium")
+    ap.add_argument("--scene", default=None, help="path of a .rtscene file to render instead of a procedural workload")
+    ap.add_argument("--res", default="1920x1080")
+    ap.add_argument("--max-bounces", type=int, default=4)
+    ap.add_argument("--term-prob", type=float, default=0.5)
+    ap.add_argument("--stack-depth", type=int, default=23)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--tex", type=int, default=1024)
+    ap.add_argument("--tiles", type=int, default=1)
+    ap.add_argument("--terrain-n", type=int, default=60)
+    ap.add_argument("--view", default="ground", choices=("ground", "top"), help="terrain camera: near the first tiles, or looking down on the whole tiling")
+    ap.add_argument("--instanced", action="store_true", help="terrain tiles as instanced primitives instead of one merged BVH")
+    ap.add_argument("--enable-sun", action="store_true", help="the sun option (shadow rays); not the reference's live behaviour")
+    ap.add_argument("--random-rays", type=int, default=0, help="also time this many uniformly random rays over the scene's extent through rthip_trace_rays")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call latency measurement")
+    ap.add_argument("--opaque", action="store_true", help="diagnostic: treat MASK/BLEND materials as opaque")
+    ap.add_argument("--first-frame", type=int, default=1, help="frame index of the first timed step (RNG key)")
+    ap.add_argument("--pmc-key", default=None, help="file the run under this workload name in profiles/pmc_per_ray.json (e.g. when it is rendered from a baked --scene)")
+    ap.add_argument("--save-scene", default=None, help="write the workload as a .rtscene file and exit (no GPU needed)")
+    return ap.parse_args(argv)
+
+
+def visible_gpus():
+    """GPUs this process could use, counted without initialising any of them."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def resolve_launch(args, env=os.environ):
+    """How this invocation runs.  Returns ("rank", world, rank, local_rank) when it is one rank of
+    a launcher's world, ("single",) for one GPU, ("group", n) for --one-process, or
+    ("spawn", cmd) when it has to start the ranks itself.  Raises SystemExit(2) instead of ever
+    running on fewer GPUs than --gpus names."""
+    n = args.gpus
+    if n < 1:
+        raise SystemExit(2)
+    in_launcher = "RANK" in env and "WORLD_SIZE" in env
+    if in_launcher:
+        world = int(env["WORLD_SIZE"])
+        if world != n:
+            print(f"bench.py: --gpus {n} but the launcher started WORLD_SIZE={world} ranks; refusing to report {n} GPUs", file=sys.stderr)
+            raise SystemExit(2)
+        if args.one_process:
+            print("bench.py: --one-process cannot run under a process launcher", file=sys.stderr)
+            raise SystemExit(2)
+        return ("rank", world, int(env["RANK"]), int(env.get("LOCAL_RANK", env["RANK"])))
+    if n == 1:
+        return ("single",)
+    have = visible_gpus()
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to report {n} GPUs from fewer devices", file=sys.stderr)
+        raise SystemExit(2)
+    if args.one_process:
+        return ("group", n)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return ("spawn", cmd)
 
 
 def extend_algorithmic_bytes(c):
@@ -33,59 +112,35 @@ def extend_algorithmic_bytes(c):
     return (32 * (c["prims_visited"] + 2 * c["inner_steps"]) + 36 * c["tri_tests"] + 80 * c["prims_visited"])
 
 
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_extend_summary.txt")
+def workload_key(args):
+    """Name under which the hardware-counter figures of this workload are filed in profiles/pmc_per_ray.json."""
+    if args.pmc_key:
+        return args.pmc_key
+    if args.scene:
+        return "scene:" + os.path.basename(args.scene)
+    k = f"{args.workload}-{args.res}-b{args.max_bounces}"
+    if args.workload == "terrain":
+        k += f"-t{args.tiles}-{args.view}" + ("-inst" if args.instanced else "")
+    if args.workload == "atrium" and (args.detail != 1.0 or args.tex != 1024):
+        k += f"-d{args.detail}-x{args.tex}"
+    if args.opaque:
+        k += "-opaque"
+    if args.enable_sun:
+        k += "-sun"
+    return k
 
 
-def profiled_extend_traffic():
-    """HBM-side bytes per k_extend launch from the committed rocprofv3 PMC passes of this same
-    default command (tools/prof.sh): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-    tallies 128-byte requests at 64 bytes, so it is doubled.  None when the summary is missing."""
+def pmc_figures(key):
+    """Per-ray hardware-counter figures of k_extend for this workload, from the committed
+    rocprofv3 passes (tools/prof.sh writes them); None when the workload has not been profiled."""
     try:
-        text = open(PROFILE_SUMMARY).read()
-    except OSError:
+        return json.load(open(PMC_FILE)).get(key)
+    except (OSError, ValueError):
         return None
-    block = text.split("\n  void k_extend<false, true, false>(ExtArgs)\n")
-    if len(block) < 2:
-        return None
-    vals = {}
-    for line in block[-1].split("\n\n")[0].splitlines():
-        f = line.split()
-        if len(f) >= 5 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[f[0]] = float(f[-1])
-    if len(vals) != 2:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-
-
-PIPELINE_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_extend_memory_pipeline.txt")
-
-
-def profiled_extend_units():
-    """Busy fractions of the CU's vector-memory units during k_extend, from the committed PMC pass
-    of the default command (tools/prof_mem.sh): busy cycles summed over the 256 CUs / (cycles of the
-    dispatch x 256).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.  None when the summary is missing."""
-    try:
-        text = open(PIPELINE_SUMMARY).read()
-    except OSError:
-        return None
-    block = text.split("\n  void k_extend<false, true, false>(ExtArgs)\n")
-    if len(block) < 2:
-        return None
-    vals = {}
-    for line in block[-1].split("\n\n")[0].splitlines():
-        f = line.split()
-        if len(f) >= 5 and f[0] in ("GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum", "TD_TD_BUSY_sum", "TD_TC_STALL_sum"):
-            vals[f[0]] = float(f[-1])
-    if len(vals) != 4 or vals["GRBM_GUI_ACTIVE"] <= 0:
-        return None
-    cu_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
-    return {"address_unit_busy": round(vals["TA_TA_BUSY_sum"] / cu_cycles, 3),
-            "data_return_busy": round(vals["TD_TD_BUSY_sum"] / cu_cycles, 3),
-            "data_return_stalled_on_l1_miss": round(vals["TD_TC_STALL_sum"] / cu_cycles, 3),
-            "source": "profiles/r01_final_extend_memory_pipeline.txt"}
 
 
 def build_workload(args):
+    from raytracer_amd import procedural
     if args.scene:
         # a baked scene (e.g. Khronos Sponza prepared elsewhere); its own first camera is used
         from raytracer_amd import host
@@ -100,8 +155,8 @@ def build_workload(args):
         scene = procedural.blob_scene()
         name = "suzanne-proxy blob"
     elif args.workload == "terrain":
-        scene = procedural.terrain_scene(tiles=args.tiles, n=args.terrain_n, instanced=args.instanced)
-        name = f"terrain tiled {args.tiles}x{args.tiles}" + (" as instances" if args.instanced else "")
+        scene = procedural.terrain_scene(tiles=args.tiles, n=args.terrain_n, instanced=args.instanced, view=args.view)
+        name = f"terrain tiled {args.tiles}x{args.tiles}" + (" as instances" if args.instanced else "") + f", {args.view} view"
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     return scene, name
@@ -111,11 +166,12 @@ def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
     """Times the CPU oracle (the build's own restatement, not the reference binary) on the first
     frames of the same workload, all host threads the box grants this process.  One untimed frame
     sizes the run to about target_seconds of CPU work."""
+    import numpy as np
     from oracle import orc
     env = arrays["env"]
     sc = orc.make_scene(arrays["tris"], arrays["tri_exts"], arrays["nodes"], arrays["prims"],
                         arrays["texels"], env, env.shape[1], env.shape[0])
-    op = orc.Params(params.max_bounces, params.term_prob, params.aperture_radius, params.stack_depth, 0)
+    op = orc.Params(params.max_bounces, params.term_prob, params.aperture_radius, params.stack_depth, params.enable_sun)
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     h = int(np.ascontiguousarray(uniforms).view(np.uint8).reshape(-1)[580:584].view(np.uint32)[0])
     t0 = time.perf_counter()
@@ -127,46 +183,70 @@ def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
     dt = time.perf_counter() - t0
     rate = r["counters"]["rays"] / dt
     return {"value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "lavapipe": "unavailable (no cargo and no Vulkan ICD on this box): the reference shader itself was not run; "
+                        "this is the build's own C restatement of it",
             "sample": f"frames 1..{frames} of the same workload, all {h} rows ({r['counters']['rays']} rays, {dt:.1f} s)"}
 
 
+def random_rays_bench(ctx, arrays, n, params, device):
+    """n uniformly random rays over the scene's whole extent through rthip_trace_rays: nothing two
+    neighbouring lanes touch is shared below the top of the tree.  Returns the extend stage's rate."""
+    import numpy as np
+    v = arrays["tris"]["v"][:, :, :3].reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    rng = np.random.default_rng(1)
+    o = (lo + rng.random((n, 3), dtype=np.float32) * (hi - lo)).astype(np.float32)
+    o[:, 2] = hi[2] + 1.0 + 50.0 * rng.random(n, dtype=np.float32)   # start above the terrain
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = device.default_params(stack_depth=params.stack_depth, flags=device.FLAG_TIMING)
+    ctx.trace_rays(o[:65536], d[:65536], None, p)   # warm-up, sizes the staging
+    ctx.trace_rays(o, d, None, p)
+    ctx.reset_timing()
+    ctx.reset_counters()
+    pc = device.default_params(stack_depth=params.stack_depth, flags=device.FLAG_TIMING)
+    q = ctx.trace_rays(o, d, None, pc)
+    t = ctx.timing()["extend"]
+    pcount = device.default_params(stack_depth=params.stack_depth, flags=device.FLAG_COUNTERS)
+    ctx.trace_rays(o, d, None, pcount)
+    c = ctx.counters()
+    ms = t["ms"] / max(t["launches"], 1)
+    return {"rays": n, "hit_fraction": round(float((q["tri"] >= 0).mean()), 4), "extend_ms": round(ms, 4),
+            "mrays_per_s": round(n / (ms * 1e-3) / 1e6, 1) if ms > 0 else None,
+            "algorithmic_gbs": round(extend_algorithmic_bytes(c) / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+            "inner_steps_per_ray": round(c["inner_steps"] / n, 2), "tri_tests_per_ray": round(c["tri_tests"] / n, 2)}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="atrium")
-    ap.add_argument("--scene", default=None, help="path of a .rtscene file to render instead of a procedural workload")
-    ap.add_argument("--res", default="1920x1080")
-    ap.add_argument("--max-bounces", type=int, default=4)
-    ap.add_argument("--term-prob", type=float, default=0.5)
-    ap.add_argument("--stack-depth", type=int, default=23)
-    ap.add_argument("--detail", type=float, default=1.0)
-    ap.add_argument("--tex", type=int, default=1024)
-    ap.add_argument("--tiles", type=int, default=1)
-    ap.add_argument("--terrain-n", type=int, default=60)
-    ap.add_argument("--instanced", action="store_true", help="terrain tiles as instanced primitives instead of one merged BVH")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--opaque", action="store_true", help="diagnostic: treat MASK/BLEND materials as opaque")
-    ap.add_argument("--first-frame", type=int, default=1, help="frame index of the first timed step (RNG key)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.save_scene:
+        scene, name = build_workload(args)
+        scene.save(args.save_scene)
+        print(f"wrote {args.save_scene}: {name}")
+        return 0
+    launch = resolve_launch(args)
+    if launch[0] == "spawn":
+        # the ranks are children of this process; nothing here has touched a GPU
+        return subprocess.run(launch[1]).returncode
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = args.gpus
-    if world != n_gpus and world > 1:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
-    # under torch.distributed.run the collective path is used even for one rank, so that it can
-    # be exercised on a one-GPU box
-    distributed = world > 1 or "RANK" in os.environ
+    import numpy as np
+    from raytracer_amd import device
 
+    mode = launch[0]
+    world, rank, local_rank = 1, 0, 0
     torch = dist = None
-    if distributed:
+    grp = None
+    if mode == "rank":
+        _, world, rank, local_rank = launch
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(2)
+    elif mode == "group":
+        world = launch[1]
 
     res = tuple(int(v) for v in args.res.lower().split("x"))
     scene, workload_name = build_workload(args)
@@ -174,84 +254,181 @@ def main():
     if args.opaque:
         arrays["prims"]["material"]["alpha_settings"] = 0
     uniforms = scene.frame_uniforms(res, frame=1, reject_hist=1)
+    n_pix = res[0] * res[1]
 
-    ctx = device.Context(local_rank if distributed else 0)
-    ctx.upload_scene(arrays)
-    ctx.set_frame_uniforms(uniforms)
-    accum_t = None
-    if distributed:
-        accum_t = torch.zeros(res[0] * res[1] * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
-        ctx.bind_accum(accum_t.data_ptr(), res[0] * res[1])
-
-    base = dict(max_bounces=args.max_bounces, term_prob=args.term_prob, stack_depth=args.stack_depth)
+    base = dict(max_bounces=args.max_bounces, term_prob=args.term_prob, stack_depth=args.stack_depth,
+                enable_sun=1 if args.enable_sun else 0)
     p_plain = device.default_params(flags=device.FLAG_TIMING, **base)
     p_count = device.default_params(flags=device.FLAG_COUNTERS, **base)
-    K, W = args.steps, args.warmup
-    first = args.first_frame + rank
-    stride = world
+    p_bare = device.default_params(**base)
+    W = args.warmup
+    strong = args.spp_total > 0
+    total_frames = args.spp_total if strong else args.steps * world
+    K = args.spp_total if strong else args.steps          # steps reported: whole-job frames (strong) or frames per GPU (weak)
 
-    ctx.reserve(K)  # size the work buffers for the timed call now, not inside it
-    # warm-up (untimed)
-    if W > 0:
-        ctx.render(first, W, stride, device.default_params(**base))
-    ctx.synchronize()
-    ctx.reset_timing()
-    ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
+    def stripe(r):  # frames of rank r: first, count (stride = world)
+        first = args.first_frame + r
+        count = (total_frames - r + world - 1) // world if total_frames > r else 0
+        return first, count
 
-    def sync_all():
+    devices_seen = [0]
+    if mode == "group":
+        from raytracer_amd import group
+        grp = group.Group(list(range(world)))
+        if grp.size != args.gpus:
+            raise SystemExit(2)
+        devices_seen = list(range(grp.size))
+        grp.upload_scene(arrays)
+        grp.set_frame_uniforms(uniforms)
+        ctx = grp.contexts[0]
+        for c in grp.contexts:
+            c.reserve(max(stripe(0)[1], 1))
+        if W > 0:
+            grp.render(args.first_frame, W * world, p_bare)
+        grp.synchronize()
+        for c in grp.contexts:
+            c.reset_timing()
+        grp.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
+        grp.synchronize()
+        t0 = time.perf_counter()
+        grp.render(args.first_frame, total_frames, p_plain)
+        grp.reduce(0)                                  # synchronous: every GPU's stream is drained
+        elapsed = time.perf_counter() - t0
+        timing = ctx.timing()
+        for c in grp.contexts:
+            c.reset_counters()
+        grp.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
+        grp.render(args.first_frame, total_frames, p_count)
+        grp.synchronize()
+        per_rank = [c.counters() for c in grp.contexts]
+        counters = per_rank[0]
+        rays_local = counters["rays"]
+        rays_total = sum(c["rays"] for c in per_rank)
+    else:
+        ctx = device.Context(local_rank)
+        ctx.upload_scene(arrays)
+        ctx.set_frame_uniforms(uniforms)
+        accum_t = None
+        if mode == "rank":
+            accum_t = torch.zeros(n_pix * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+            ctx.bind_accum(accum_t.data_ptr(), n_pix)
+            # which devices really take part: one entry per rank, gathered from every rank
+            mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=f"cuda:{local_rank}")
+            seen = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(seen, mine)
+            devices_seen = sorted({int(t.item()) for t in seen})
+        first, count = stripe(rank)
+        ctx.reserve(max(count, 1))  # size the work buffers for the timed call now, not inside it
+        if W > 0:
+            ctx.render(first, W, world, p_bare)
         ctx.synchronize()
-        if distributed:
+        ctx.reset_timing()
+        ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
+
+        def sync_all():
+            ctx.synchronize()
+            if mode == "rank":
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        sync_all()
+        t0 = time.perf_counter()
+        ctx.render(first, count, world, p_plain)
+        ctx.synchronize()
+        if mode == "rank":
+            dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if mode == "rank":
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        timing = ctx.timing()
 
-    sync_all()
-    t0 = time.perf_counter()
-    ctx.render(first, K, stride, p_plain)
-    ctx.synchronize()
-    if distributed:
-        dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    timing = ctx.timing()
+        # identical frames again with counters on: the RNG is keyed by (pixel, frame), so the work
+        # is the same work; counting is kept out of the timed region
+        ctx.reset_counters()
+        ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
+        ctx.render(first, count, world, p_count)
+        counters = ctx.counters()
+        rays_local = counters["rays"]
+        rays_total = rays_local
+        if mode == "rank":
+            rt = torch.tensor([rays_local], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+            rays_total = int(rt.item())
 
-    # identical frames again with counters on: the RNG is keyed by (pixel, frame), so the work
-    # is the same work; counting is kept out of the timed region
-    ctx.reset_counters()
-    ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
-    ctx.render(first, K, stride, p_count)
-    counters = ctx.counters()
-    rays_local = counters["rays"]
-    rays_total = rays_local
-    if distributed:
-        rt = torch.tensor([rays_local], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
-        rays_total = int(rt.item())
+    n_gpus = len(devices_seen) if mode != "single" else 1
+    if n_gpus != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the ranks ran on {n_gpus} distinct device(s): {devices_seen}", file=sys.stderr)
+        raise SystemExit(2)
 
-    copy_gbs = ctx.copy_bandwidth() if rank == 0 else 0.0
-    default_run = (args.scene is None and args.workload == "atrium" and args.res == "1920x1080" and args.max_bounces == 4 and args.detail == 1.0
-                   and args.tex == 1024 and K % 64 == 0 and not args.opaque and os.environ.get("RTHIP_FRAMES_IN_FLIGHT") is None)
     if rank == 0:
+        local_frames = max(stripe(0)[1], 1)
+        copy_gbs = ctx.copy_bandwidth()
         ext = timing["extend"]
         ext_bytes = extend_algorithmic_bytes(counters)
         launches = max(ext["launches"], 1)
         avg_ms = ext["ms"] / launches
-        achieved = (ext_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        rays_per_launch = rays_local / launches
+        algorithmic_gbs = (ext_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        key = workload_key(args)
+        pmc = pmc_figures(key)
+        roof = {
+            # a byte-moving f32/integer kernel with no contraction: HBM is the roofline it is classed
+            # under.  `achieved` is the HBM-side traffic the hardware counters saw for this workload
+            # (per ray, from the committed rocprofv3 passes) x the rays of a launch / the launch time
+            # measured here with HIP events; `frac` is that over the vendor peak.
+            "bound": "hbm",
+            "kernel": "k_extend",
+            "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "peak_stream_copy": round(copy_gbs, 1),
+            "launches": ext["launches"],
+            "avg_launch_ms": round(avg_ms, 5),
+            "rays_per_launch": round(rays_per_launch, 1),
+            # what the caches deliver: the bytes the traversal needs by the counting rule above over
+            # the same time.  A delivery rate of L1 + L2 + Infinity Cache + HBM together, not a
+            # fraction of any one peak.
+            "algorithmic_bytes_per_launch": round(ext_bytes / launches, 1),
+            "algorithmic_gbs": round(algorithmic_gbs, 2),
+            "pmc_workload": key,
+        }
+        if pmc and avg_ms > 0:
+            hbm_bytes = (pmc["fetch_bytes_per_ray"] + pmc["write_bytes_per_ray"]) * rays_per_launch
+            hbm_gbs = hbm_bytes / (avg_ms * 1e-3) / 1e9
+            l2_gbs = pmc["l2_read_bytes_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / 1e9
+            roof.update({
+                "achieved": round(hbm_gbs, 1),
+                "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                "frac_of_stream_copy": round(hbm_gbs / copy_gbs, 4) if copy_gbs > 0 else None,
+                "traffic": round(hbm_bytes, 1),
+                "traffic_over_algorithmic": round(hbm_bytes / max(ext_bytes / launches, 1.0), 4),
+                "traffic_source": pmc["source"],
+                "l2_hit_rate": pmc.get("l2_hit_rate"),
+                "l2_to_l1_gbs": round(l2_gbs, 1),
+                "l2_frac": round(l2_gbs / L2_PEAK_GBS, 4),
+                # what the stage is measured to be limited by: busy fractions of the CU's
+                # vector-memory units (address unit TA, data-return unit TD) over the dispatch
+                "measured_limiter": {"unit": pmc.get("limiter_unit"), "busy_frac": pmc.get("limiter_busy_frac"),
+                                     "address_unit_busy": pmc.get("ta_busy"), "data_return_busy": pmc.get("td_busy"),
+                                     "data_return_stalled_on_l1_miss": pmc.get("td_tc_stall"),
+                                     "valu_lane_utilisation": pmc.get("valu_lane_utilisation")},
+            })
         out = {
-            "metric": "Mrays/sec (Sponza 1080p, 4 bounces)",
+            "metric": ("Mrays/sec (Sponza 1080p, 4 bounces) -- measured on a procedural Sponza-proxy atrium"
+                       if args.workload == "atrium" and not args.scene else f"Mrays/sec ({workload_name}, {args.max_bounces} bounces)"),
             "value": round(rays_total / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": n_gpus,
+            "ranks_seen": world,
+            "devices_seen": devices_seen,
             "steps": K,
             "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "ms_per_step": round(elapsed / max(local_frames if not strong else K, 1) * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -266,29 +443,14 @@ def main():
                 "max_bounces": args.max_bounces,
                 "term_prob": args.term_prob,
                 "depth_of_field": True,
-                "parallelism": f"spp-split x{n_gpus}" if n_gpus > 1 else "single",
+                "sun": bool(args.enable_sun),
+                "triangle_layout": "48-byte (p0, e1, e2) records, three 12-byte loads per test (not 9-plane SoA)",
+                "parallelism": (f"spp-split x{n_gpus}" + (" (one process, librthip_group)" if mode == "group" else "")) if n_gpus > 1 else "single",
+                "frames_total": total_frames,
             },
-            "rays_per_step_per_gpu": round(rays_local / K, 1),
-            "stage_ms_per_step": {s: round(timing[s]["ms"] / K, 4) for s in ("generate", "cull", "extend", "shade", "accumulate")},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_extend",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "peak_stream_copy": round(copy_gbs, 1),
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                # PMC counters cannot be read from inside the run; this is the figure of the committed
-                # profile of the default command (same workload, same 64-frame launches)
-                "traffic": profiled_extend_traffic() if default_run else None,
-                "traffic_source": "profiles/r01_final_extend_summary.txt" if default_run else None,
-                "launches": ext["launches"],
-                "avg_launch_ms": round(avg_ms, 5),
-                "algorithmic_bytes_per_launch": round(ext_bytes / launches, 1),
-                # what the kernel is measured to be limited by: the CU's vector-memory front end,
-                # not HBM (the algorithmic bytes are served by L1, L2 and the Infinity Cache)
-                "measured_limiter": profiled_extend_units() if default_run else None,
-            },
+            "rays_per_step_per_gpu": round(rays_local / local_frames, 1),
+            "stage_ms_per_step": {s: round(timing[s]["ms"] / local_frames, 4) for s in ("generate", "cull", "extend", "shade", "shadow", "accumulate")},
+            "roofline": roof,
             "counters_per_ray": {k: round(counters[k] / max(rays_local, 1), 3)
                                  for k in ("prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests")},
             "extend_simd_utilisation": {
@@ -298,15 +460,38 @@ def main():
                 "rounds_per_batch": round((counters["rounds_prim"] + counters["rounds_inner"] + counters["rounds_leaf"]) / max(counters["batches"], 1), 1),
             },
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if mode == "single" and not args.no_single_frame:
+            # what the reference's frame() does (main.rs:356-407): one sample per call, then present
+            n_single = 20
+            ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
+            for f in range(3):
+                ctx.render(args.first_frame + f, 1, 1, p_bare)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for f in range(n_single):
+                ctx.render(args.first_frame + 3 + f, 1, 1, p_bare)
+                ctx.synchronize()
+            out["ms_per_frame_single"] = round((time.perf_counter() - t0) / n_single * 1e3, 4)
+            t0 = time.perf_counter()
+            for f in range(n_single):
+                ctx.render(args.first_frame + 3 + n_single + f, 1, 1, p_bare)
+                ctx.resolve()
+            out["ms_per_frame_single_with_resolve_to_host"] = round((time.perf_counter() - t0) / n_single * 1e3, 4)
+        if args.random_rays > 0 and mode == "single":
+            out["random_rays"] = random_rays_bench(ctx, arrays, args.random_rays, p_plain, device)
+        if mode == "single" and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arrays, uniforms, p_plain)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
-    if distributed:
+    if grp is not None:
+        grp.close()
+    else:
+        ctx.close()
+    if mode == "rank":
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

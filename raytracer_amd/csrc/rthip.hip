@@ -1008,6 +1008,7 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
 
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
+    const bool timing = (P.flags & RTHIP_FLAG_TIMING) != 0;
     const bool multi = c->sc.n_chunks > 1u;
     const bool deep = P.stack_depth > rt_lds_levels(multi);
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
@@ -1044,9 +1045,13 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
         ca.in = ea.in;
         ca.masks = reinterpret_cast<uint4*>(d_hits);
         ca.count_in = d_ctl;
+        StageTimer tm(c, timing, RTHIP_STAGE_CULL);
         hipLaunchKernelGGL(k_cull, dim3((uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n + 255) / 256)), dim3(256), 0, c->stream, ca);
     }
-    extend_launch(count, deep, multi, grid, c->stream, ea);
+    {
+        StageTimer tm(c, timing, RTHIP_STAGE_EXTEND);
+        extend_launch(count, deep, multi, grid, c->stream, ea);
+    }
     std::vector<float> hits((size_t)n * 4);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(hits.data(), d_hits, sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream);

@@ -346,12 +346,14 @@ def terrain_mesh(n=60, size=40.0, seed=7):
     return grid(n, n, (size, size), height=height, uv_scale=8.0)
 
 
-def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False):
+def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False, view="ground"):
     """Stand-in for resources/simple_terrain.glb (a ~7 k-triangle plane plus a ~1 k-triangle
     object, own camera) and, with tiles > 1, for its tiling into one large primitive
     (tiles^2 copies merged into one BVH): the HBM-resident traversal stress case.  With
     instanced=True the tiles stay 2 * tiles^2 primitives that share two BVHs: the stress case
-    for the number of primitives."""
+    for the number of primitives.  view="ground" is the glTF-style camera near the first tiles
+    (it sees a sliver of a large tiling); view="top" looks down on the whole tiling from a height at
+    which the image is as wide as the terrain, so that every pixel lands in another part of it."""
     size = 40.0
     t = terrain_mesh(n, size)
     rock = uv_sphere(22, 23, radius=2.0)  # 968 triangles
@@ -380,7 +382,14 @@ def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False):
         m = merge(parts)
         s.add_primitive(m[0], m[1], normals=m[2], uv0=m[3], material=material(albedo=(0.8, 0.8, 0.8, 1), roughness=1.0))
     s.set_env(sky_env(*env_size))
-    s.add_camera(host.Camera.look((-38.0, -6.0, 11.0), yaw=0.15, pitch=np.radians(-14), fovy=0.3562, focus=50.0))
+    if view == "top":
+        fovy = np.radians(60.0)
+        height = (tiles * size / 2) / (np.tan(fovy / 2) * 16.0 / 9.0)   # 16:9: the width of the image spans the tiling
+        # camera_ray's basis needs forward x (0,0,1) != 0 (shader.wgsl:746): not quite straight down
+        s.add_camera(host.Camera.look((-height * np.tan(np.radians(5.0)), 0.0, height), yaw=0.0, pitch=np.radians(-85.0),
+                                      fovy=fovy, focus=height))
+    else:
+        s.add_camera(host.Camera.look((-38.0, -6.0, 11.0), yaw=0.15, pitch=np.radians(-14), fovy=0.3562, focus=50.0))
     return s
 
 
