@@ -91,7 +91,7 @@ def resolve_launch(args, env=os.environ):
             print("bench.py: --one-process cannot run under a process launcher", file=sys.stderr)
             raise SystemExit(2)
         return ("rank", world, int(env["RANK"]), int(env.get("LOCAL_RANK", env["RANK"])))
-    if n == 1:
+    if n == 1 and not args.one_process:
         return ("single",)
     have = visible_gpus()
     if have < n:
@@ -285,6 +285,7 @@ def main():
             c.reserve(max(stripe(0)[1], 1))
         if W > 0:
             grp.render(args.first_frame, W * world, p_bare)
+        grp.reduce(0)   # untimed: the first reduce creates the RCCL communicator
         grp.synchronize()
         for c in grp.contexts:
             c.reset_timing()
@@ -322,6 +323,9 @@ def main():
         if W > 0:
             ctx.render(first, W, world, p_bare)
         ctx.synchronize()
+        if mode == "rank":  # untimed: the first collective on a communicator sets up its channels
+            dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
         ctx.reset_timing()
         ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
 

@@ -66,6 +66,7 @@ struct GenArgs {
     uint32_t  res_x, res_y, tiles_x, n_tiles;
     uint32_t  first_frame, frame_stride, n_frames; // frames first, first + stride, ... share this launch
     uint32_t  n_pixels;
+    uint32_t  spread_shift;       // 0: a run of 64 slots is one 8x8 tile; 2: four 4x4 blocks of four far-apart tiles; 4: sixteen 2x2 blocks
     unsigned long long* counters; // may be null
 };
 
@@ -87,8 +88,24 @@ __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
     const uint32_t run = gid >> 6, l = gid & 63u;
     const uint32_t tile = run / a.n_frames, fs = run - tile * a.n_frames;
     if (tile >= a.n_tiles) return;
-    const uint32_t px = (tile % a.tiles_x) * 8u + (l & 7u);
-    const uint32_t py = (tile / a.tiles_x) * 8u + (l >> 3);
+    // Which pixel of which tile lane l of the run renders.  A whole tile per run keeps a wave's
+    // rays together (they walk the same nodes), and with it their cost: the rays of a tile full of
+    // foliage all take several times the average, and the wave that holds them ends long after the
+    // others.  Calls of a few frames are too short to average that out (the launch waits for its
+    // slowest wave), so they build a run from 4 or 16 square blocks of far-apart tiles instead.
+    uint32_t t2 = tile, lx = l & 7u, ly = l >> 3;
+    if (a.spread_shift) {
+        const uint32_t sh = a.spread_shift;            // 2 or 4
+        const uint32_t q = l >> (6u - sh);             // block of the run
+        const uint32_t j = l & ((64u >> sh) - 1u);     // pixel of the block
+        const uint32_t side = 8u >> (sh >> 1);         // 4 or 2 pixels
+        const uint32_t per_row = 8u / side;
+        lx = (q % per_row) * side + (j % side);
+        ly = (q / per_row) * side + (j / side);
+        t2 = (tile + q * (a.n_tiles >> sh)) % a.n_tiles; // for every q a bijection of the tiles
+    }
+    const uint32_t px = (t2 % a.tiles_x) * 8u + lx;
+    const uint32_t py = (t2 / a.tiles_x) * 8u + ly;
     const bool valid = px < a.res_x && py < a.res_y;
     if (gid == 0) *a.count_out = per_frame * a.n_frames;
 
@@ -151,6 +168,9 @@ struct ExtArgs {
     unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped;
     uint32_t  nan_overflow;
     uint32_t  pad2;
+#ifdef RT_PROBE
+    unsigned long long* probe; // diagnostic build: per wave (start, queue seen empty, end) in 100 MHz ticks and the most steps one of its rays took
+#endif
 };
 
 // Conservative slab overlap of a world-space ray with a padded world-space box: a ray that
@@ -185,7 +205,15 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 // Queue slots a wave reserves per atomic: two runs of 64, i.e. (for camera rays) two frames of one
 // pixel tile, whose rays walk the same nodes and triangles while those are still in the L1
 // (64: 1.03 ms per frame of the atrium, 128: 1.00, 256: 1.01, 512: 1.05 -- the tail grows).
+#ifndef RT_RUN_SLOTS
 #define RT_RUN_SLOTS 128u
+#endif
+#ifndef RT_RUN_MIN
+#define RT_RUN_MIN 32u
+#endif
+#ifndef RT_RUN_DIV
+#define RT_RUN_DIV 4u
+#endif
 #ifndef RT_REFILL_LANES
 #define RT_REFILL_LANES 32
 #endif
@@ -416,9 +444,13 @@ __device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, fl
 // 8 waves 1.10, with the ray in LDS instead of re-read from the queue 1.08.)
 // The MULTI instantiation carries more per-lane state (chunk masks) and stays at seven waves with
 // 16 levels.
+#ifndef RT_LDS_LEVELS_SINGLE
 #define RT_LDS_LEVELS_SINGLE 13u
+#endif
 #define RT_LDS_LEVELS_MULTI 16u
+#ifndef RT_EXTEND_WAVES_SINGLE
 #define RT_EXTEND_WAVES_SINGLE 8
+#endif
 #define RT_EXTEND_WAVES_MULTI 7
 __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi ? RT_LDS_LEVELS_MULTI : RT_LDS_LEVELS_SINGLE; }
 #define RT_MAX_STACK 64u
@@ -476,8 +508,15 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
     unsigned long long r_prim = 0, r_inner = 0, r_leaf = 0, r_batch = 0; // wave-uniform
 
     // wave-uniform: the reserved run of queue slots not yet handed to a lane
-    uint32_t run_next = 0, run_end = 0;
+    uint32_t run_next = 0, run_end = 0, cursor_seen = 0;
     bool drained = false;
+#ifdef RT_PROBE
+    const unsigned long long pr_start = wall_clock64();
+    unsigned long long pr_drain = 0;
+    uint32_t pr_steps = 0, pr_max = 0, pr_rounds_tail = 0, pr_live_at_drain = 0;
+    uint32_t pr_n[3] = {0, 0, 0}, pr_t[3] = {0, 0, 0}; // after the drain: rounds and ticks per kind (inner, leaf, prim)
+    unsigned long long pr_mark = 0;
+#endif
 
     // per-lane
     // per-lane.  What a ray needs only between primitives is not held in registers, so that more
@@ -583,14 +622,25 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
         // ---- refill: hand reserved queue slots to the lanes that wait for a ray
         if (n_done != 0u && !drained && (n_done >= RT_REFILL_LANES || n_trav + n_scan == 0u)) {
             if (run_next == run_end) {
+                // Guided reservation: RT_RUN_SLOTS while the queue is long, then ever smaller runs
+                // (what is left, by this wave's last sight of the cursor, over twice the waves of the
+                // grid), so that the last rays of a launch are spread over all waves instead of
+                // filling the lanes of a few: the tail of a launch is the time its last-fetched
+                // batch needs, and a wave with a handful of rays is done long before one with 64.
+                const uint32_t left = n > cursor_seen ? n - cursor_seen : 0u;
+                const uint32_t want = min(RT_RUN_SLOTS, max(RT_RUN_MIN, left / (RT_RUN_DIV * 4u * gridDim.x)));
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.cursor, RT_RUN_SLOTS);
+                if (lane == 0) base = atomicAdd(a.cursor, want);
                 base = __builtin_amdgcn_readfirstlane(base);
+                cursor_seen = base + want;
                 if (base >= n) {
                     drained = true;
+#ifdef RT_PROBE
+                    pr_drain = wall_clock64();
+#endif
                 } else {
                     run_next = base;
-                    run_end = min(base + RT_RUN_SLOTS, n);
+                    run_end = min(base + want, n);
                     if (COUNT) r_batch += (run_end - run_next + 63u) >> 6;
                 }
             }
@@ -619,6 +669,10 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                         if (MULTI) cmask = ~0ull;
                         st = ST_SCAN;
                         fresh = true;
+#ifdef RT_PROBE
+                        pr_max = max(pr_max, pr_steps);
+                        pr_steps = 0;
+#endif
                         if (COUNT) c_rays++;
                         // A direction of NaNs (normalize() of a zero vector in the shading code)
                         // fails no box test and passes no triangle test: the reference walks
@@ -736,13 +790,22 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
         }
 
         if (n_trav == 0u) break; // every lane is done or idle and the queue is drained
+#ifdef RT_PROBE
+        if (drained) { if (pr_rounds_tail == 0u) pr_live_at_drain = n_trav; pr_rounds_tail++; }
+#endif
 
+#ifdef RT_PROBE
+        pr_mark = wall_clock64();
+#endif
         if (n_inner >= n_prim && n_inner >= n_leaf) {
 #pragma unroll 1
             for (int burst = 0; burst < RT_INNER_BURST; burst++) {
                 if (COUNT) r_inner++;
                 if (st == ST_INNER) {
                     if (COUNT) c_inner++;
+#ifdef RT_PROBE
+                    pr_steps++;
+#endif
                     // the sibling pair: 48 bytes of boxes and a descriptor dword per child
                     const float4* np = rec16(sc.pairs, cur_first * 2u);
                     const float4 b0 = np[0], b1 = np[1], b2 = np[2];
@@ -769,6 +832,9 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 }
                 if (__ballot(st == ST_INNER) == 0ull) break;
             }
+#ifdef RT_PROBE
+            if (drained) { pr_n[0]++; pr_t[0] += (uint32_t)(wall_clock64() - pr_mark); }
+#endif
         } else if (n_leaf >= n_prim) {
             // up to two triangles of the lane's leaf per round (leaves hold 1.8 on average): both
             // fetches are in flight together and the lane is back among the inner-node lanes a
@@ -776,6 +842,9 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
             const bool two = st == ST_LEAF && cur_count > 1u;
             if (COUNT) r_leaf += __ballot(two) ? 2u : 1u;
             if (st == ST_LEAF) {
+#ifdef RT_PROBE
+                pr_steps++;
+#endif
                 const float4* tp = rec16(tris, cur_first * 3u);
                 // 12-byte loads: the fourth lane of a triangle's rows is padding, and the return path
                 // charges a wave-level load by its width
@@ -824,9 +893,15 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 cur_count -= done;
                 if (cur_count == 0u) pop_or_finish();
             }
+#ifdef RT_PROBE
+            if (drained) { pr_n[1]++; pr_t[1] += (uint32_t)(wall_clock64() - pr_mark); }
+#endif
         } else {
             if (COUNT) r_prim++;
             if (st == ST_PRIM) {
+#ifdef RT_PROBE
+                pr_steps++;
+#endif
                 // next candidate in index order
                 uint32_t k;
                 if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
@@ -869,8 +944,24 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                     enter(root_first, root_count);
                 }
             }
+#ifdef RT_PROBE
+            if (drained) { pr_n[2]++; pr_t[2] += (uint32_t)(wall_clock64() - pr_mark); }
+#endif
         }
     }
+#ifdef RT_PROBE
+    if (a.probe) {
+        pr_max = max(pr_max, pr_steps);
+        for (int o = 32; o > 0; o >>= 1) pr_max = max(pr_max, (uint32_t)__shfl_xor((int)pr_max, o, 64));
+        if (lane == 0) {
+            unsigned long long* r = a.probe + 8ull * ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6));
+            r[4] = pr_n[0] | ((unsigned long long)pr_t[0] << 32); r[5] = pr_n[1] | ((unsigned long long)pr_t[1] << 32);
+            r[6] = pr_n[2] | ((unsigned long long)pr_t[2] << 32); r[7] = 0;
+            r[0] = pr_start; r[1] = pr_drain; r[2] = wall_clock64();
+            r[3] = (unsigned long long)pr_max | ((unsigned long long)pr_rounds_tail << 20) | ((unsigned long long)pr_live_at_drain << 44);
+        }
+    }
+#endif
     if (COUNT) {
         const unsigned long long v[8] = {c_rays, c_prims, c_inner, c_leaf, c_tri, c_alpha, c_texel, c_over};
         const int idx[8] = {C_RAYS, C_PRIMS, C_INNER, C_LEAF, C_TRI, C_ALPHA, C_TEXEL, C_OVERFLOW};

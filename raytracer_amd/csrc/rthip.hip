@@ -810,6 +810,13 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     ga.n_pixels = (uint32_t)c->n_pixels;
     ga.frame_stride = frame_stride;
     ga.counters = count ? c->d_counters : nullptr;
+    // Calls of one or two frames (an interactive host: one sample per displayed frame) are too
+    // short to average out the cost of expensive image regions over a wave's many reservations:
+    // their runs are built from 4x4 blocks of four far-apart tiles (with the guided reservations of
+    // the extend stage: 4.8 -> 4.2 ms for one 1080p frame of the atrium).  Longer calls keep whole
+    // tiles, which is worth 14 % of their throughput.  RTHIP_SPREAD (0, 2, 4) overrides for experiments.
+    int spread_env = -1;
+    if (const char* e = std::getenv("RTHIP_SPREAD")) spread_env = std::atoi(e);
 
     PathQueue q[2];
     for (int k = 0; k < 2; k++) {
@@ -861,6 +868,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         ga.count_out = c->ctrl;
         ga.first_frame = first_frame + f0 * frame_stride;
         ga.n_frames = nf;
+        const bool short_call = nf <= 2u && ga.n_tiles >= 64u;
+        ga.spread_shift = short_call ? 2u : 0u;
+        if (spread_env == 0 || ((spread_env == 2 || spread_env == 4) && ga.n_tiles >= 64u)) ga.spread_shift = (uint32_t)spread_env;
         {
             StageTimer t(c, timing, RTHIP_STAGE_GENERATE);
             hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(256), 0, c->stream, ga);
@@ -897,10 +907,29 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 if (b == 0 && cull_camera) hipLaunchKernelGGL(k_cull_camera, dim3(shade_grid), dim3(256), 0, c->stream, ca);
                 else hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
             }
+#ifdef RT_PROBE
+            // diagnostic build only (tools/tail_probe.py): per-wave timestamps of this launch appended to $RTHIP_PROBE_FILE
+            static unsigned long long* probe_buf = nullptr;
+            if (!probe_buf) (void)hipMalloc((void**)&probe_buf, sizeof(unsigned long long) * 8 * 4 * 65536);
+            ea.probe = std::getenv("RTHIP_PROBE_FILE") ? probe_buf : nullptr;
+#endif
             {
                 StageTimer t(c, timing, RTHIP_STAGE_EXTEND);
                 extend_launch(count, deep, multi, ext_grid, c->stream, ea);
             }
+#ifdef RT_PROBE
+            if (ea.probe) {
+                std::vector<unsigned long long> h((size_t)ext_grid * 32);
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipMemcpy(h.data(), probe_buf, h.size() * 8, hipMemcpyDeviceToHost);
+                if (FILE* f = std::fopen(std::getenv("RTHIP_PROBE_FILE"), "ab")) {
+                    const unsigned long long hdr[2] = {b, (unsigned long long)ext_grid * 4};
+                    std::fwrite(hdr, 8, 2, f);
+                    std::fwrite(h.data(), 8, h.size(), f);
+                    std::fclose(f);
+                }
+            }
+#endif
             ShadeArgs sa{};
             sa.sc = c->sc;
             sa.in = q[b & 1];

@@ -109,3 +109,31 @@ def test_two_striped_contexts_hold_the_samples_of_one(box):
     ref = single(s, a, 1, 9)
     assert np.all(total[..., 3] == 9.0)
     np.testing.assert_allclose(total, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_group_of_two_gpus_equals_one_context(box):
+    """Two real GPUs: frames striped 1,3,5,... and 2,4,6,..., one ncclReduce over xGMI to GPU 1 and
+    then to GPU 0; a short render (fewer frames than GPUs) leaves the frame-less GPU able to be root."""
+    if device.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    s, a = box
+    g = group.Group([0, 1])
+    try:
+        g.upload_scene(a)
+        g.set_frame_uniforms(s.frame_uniforms(RES, frame=1, reject_hist=1))
+        g.render(1, 13, device.default_params())
+        g.reduce(0)
+        got = g.contexts[0].read_accum()
+        np.testing.assert_allclose(got, single(s, a, 1, 13), rtol=1e-5, atol=1e-5)
+        assert np.all(got[..., 3] == 13.0)
+        # one frame for two GPUs, root = the GPU that got none; then more samples on top
+        g.set_frame_uniforms(s.frame_uniforms(RES, frame=1, reject_hist=1))
+        g.render(1, 1, device.default_params())
+        g.reduce(1)
+        g.set_frame_uniforms(s.frame_uniforms(RES, frame=2, reject_hist=0))
+        g.render(2, 4, device.default_params())
+        g.reduce(1)
+        got = g.contexts[1].read_accum()
+        np.testing.assert_allclose(got, single(s, a, 1, 5), rtol=1e-5, atol=1e-5)
+    finally:
+        g.close()
