@@ -1,5 +1,5 @@
 """The reference's own bundled scenes (resources/*.gltf|glb + trail.hdr, baked into tests/golden by
-tools/bake_reference_assets.py) through the HIP path, against the CPU oracle on the same arrays.
+tests/tools/bake_reference_assets.py) through the HIP path, against the CPU oracle on the same arrays.
 
 Configurations 1 and 2 of the benchmark list are run exactly as named: Box.gltf 512x512 1 spp and
 suzanne.glb 512x512 64 spp with trail.hdr, default camera (input.rs:202-219), reference

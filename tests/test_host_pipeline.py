@@ -234,7 +234,7 @@ def test_scene_cache_round_trip(tmp_path):
 
 def test_baked_reference_fixtures_load_and_match_the_mounted_assets(reference_resources):
     """tests/golden/ref_*.rtscene.gz are what this build's host pipeline makes of the reference's
-    bundled scenes (tools/bake_reference_assets.py); with the reference mounted, loading the
+    bundled scenes (tests/tools/bake_reference_assets.py); with the reference mounted, loading the
     assets again gives the same bytes, and trail.hdr decodes to the floats the RGBE fixture gives."""
     from util import REFERENCE_SCENES, load_reference_scene, reference_env
     names = {"box": "Box.gltf", "suzanne": "suzanne.glb", "simple_terrain": "simple_terrain.glb",

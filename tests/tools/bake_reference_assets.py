@@ -2,7 +2,7 @@
 """Bakes the scenes that ship with the reference into fixtures under tests/golden/, so that the
 GPU box -- which has no copy of the reference -- can run the HIP path on them.
 
-    python tools/bake_reference_assets.py [--reference-dir /root/reference]
+    python tests/tools/bake_reference_assets.py [--reference-dir /root/reference]
 
 For each of resources/Box.gltf, suzanne.glb, simple_terrain.glb, simple_with_camera.glb: the
 flat arrays this build's host pipeline (librthost: glTF load, axis change, Bikker BVH build,
@@ -23,7 +23,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

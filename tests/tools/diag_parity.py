@@ -1,6 +1,6 @@
 """Diagnostic: GPU vs oracle agreement per scene and bounce limit (run on the GPU box)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import orc

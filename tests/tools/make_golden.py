@@ -3,7 +3,7 @@
 The reference has no tests or golden vectors and cannot be run here, so these fixtures pin the
 ORACLE (regression: a later edit of the oracle or of the host builder that changes them is
 flagged), not the reference.  The RNG vectors were derived by hand from shader.wgsl:641-659
-with exact u32 arithmetic.  Run from the repo root:  python tools/make_golden.py
+with exact u32 arithmetic.  Run from the repo root:  python tests/tools/make_golden.py
 """
 import json
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -27,7 +27,7 @@ def tonemapped(accum):
     return orc.resolve(accum).astype(np.float64)[..., :3] / 255.0
 
 
-# ---- the reference's own assets, baked by tools/bake_reference_assets.py ---------------------
+# ---- the reference's own assets, baked by tests/tools/bake_reference_assets.py ---------------------
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REFERENCE_SCENES = {"box": "ref_box.rtscene.gz", "suzanne": "ref_suzanne.rtscene.gz",
