@@ -13,6 +13,8 @@
 //   env (rgba32f), tri_order (u32 per triangle), cameras (13 f32 each: rthost_camera).
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <string>
 
 #include "rthost_internal.h"
 
@@ -76,7 +78,16 @@ extern "C" int rthost_scene_save(const rthost_scene* sp, const char* path) {
     return RTHOST_OK;
 }
 
+static int load_cache_body(rthost_scene* sp, const char* path);
 extern "C" int rthost_scene_load_cache(rthost_scene* sp, const char* path) {
+    try {
+        return load_cache_body(sp, path);
+    } catch (const std::exception& e) { // an allocation the file's (checked) sizes ask for can still fail
+        rthost::set_error(std::string("scene_load_cache: ") + e.what());
+        return RTHOST_ERR_LIMIT;
+    }
+}
+static int load_cache_body(rthost_scene* sp, const char* path) {
     if (!sp || !path) { rthost::set_error("scene_load_cache: null argument"); return RTHOST_ERR_INVALID; }
     FILE* f = std::fopen(path, "rb");
     if (!f) { rthost::set_error(std::string("scene_load_cache: cannot open ") + path); return RTHOST_ERR_IO; }
@@ -88,6 +99,13 @@ extern "C" int rthost_scene_load_cache(rthost_scene* sp, const char* path) {
     std::fseek(f, 0, SEEK_END);
     const long long file_len = std::ftell(f);
     std::fseek(f, (long)sizeof h, SEEK_SET);
+    // header counts are untrusted: bound them first, so that none of the products below can wrap
+    // (2^31 records is also what the device library accepts)
+    if (h.n_tris >= (1ull << 31) || h.n_nodes >= (1ull << 31) || h.n_texels >= (1ull << 34) || h.env_w > 65536u || h.env_h > 65536u || h.n_cameras > 65536u) {
+        std::fclose(f);
+        rthost::set_error(std::string("scene_load_cache: ") + path + " has counts beyond what a scene can hold");
+        return RTHOST_ERR_FORMAT;
+    }
     auto padded = [](unsigned long long b) { return (b + 15ull) & ~15ull; };
     const unsigned long long need = sizeof h + padded(48ull * h.n_tris) + padded(96ull * h.n_tris) + padded(32ull * h.n_nodes) +
                                     padded(240ull * h.n_prims) + padded(4ull * h.n_texels) + padded(16ull * h.env_w * h.env_h) +

@@ -198,7 +198,9 @@ bool get_accessor(Doc& d, int64_t idx, Accessor& a) {
     const Json& j = accs->arr[idx];
     if (j.has("sparse")) { d.err = "sparse accessors are not supported"; return false; }
     a.comp_type = (int)j.integer("componentType", 0);
-    a.count = (size_t)j.integer("count", 0);
+    const int64_t count_i = j.integer("count", 0), acc_off_i = j.integer("byteOffset", 0);
+    if (count_i < 0 || acc_off_i < 0) { d.err = "accessor with a negative count or byteOffset"; return false; }
+    a.count = (size_t)count_i;
     a.normalized = j.get("normalized") && j.get("normalized")->b;
     const std::string type = j.string("type");
     a.n_comp = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
@@ -210,11 +212,19 @@ bool get_accessor(Doc& d, int64_t idx, Accessor& a) {
     const Json& bv = bvs->arr[bv_idx];
     const int64_t buf = bv.integer("buffer", -1);
     if (buf < 0 || (size_t)buf >= d.buffers.size()) { d.err = "bufferView.buffer out of range"; return false; }
-    const size_t off = (size_t)bv.integer("byteOffset", 0) + (size_t)j.integer("byteOffset", 0);
-    const size_t bstride = (size_t)bv.integer("byteStride", 0);
-    a.stride = bstride ? bstride : cs * a.n_comp;
+    const int64_t bv_off_i = bv.integer("byteOffset", 0), stride_i = bv.integer("byteStride", 0);
+    if (bv_off_i < 0 || stride_i < 0) { d.err = "bufferView with a negative byteOffset or byteStride"; return false; }
     const std::vector<uint8_t>& b = d.buffers[buf];
-    if (a.count && off + (a.count - 1) * a.stride + cs * a.n_comp > b.size()) { d.err = "accessor exceeds its buffer"; return false; }
+    // file-supplied numbers: every step is checked by subtraction, so that no sum or product can wrap
+    if ((size_t)bv_off_i > b.size() || (size_t)acc_off_i > b.size() - (size_t)bv_off_i) { d.err = "accessor exceeds its buffer"; return false; }
+    const size_t off = (size_t)bv_off_i + (size_t)acc_off_i;
+    const size_t bstride = (size_t)stride_i;
+    const size_t elem = cs * a.n_comp;
+    a.stride = bstride ? bstride : elem;
+    if (a.count) {
+        const size_t room = b.size() - off;
+        if (elem > room || (a.count - 1) > (room - elem) / a.stride) { d.err = "accessor exceeds its buffer"; return false; }
+    }
     a.data = b.data() + off;
     return true;
 }
@@ -283,8 +293,10 @@ struct Loader {
             if (!bvs || (size_t)bv_idx >= bvs->size()) return fail_doc(d, "image bufferView out of range");
             const Json& bv = bvs->arr[bv_idx];
             const int64_t buf = bv.integer("buffer", -1);
-            const size_t off = (size_t)bv.integer("byteOffset", 0), len = (size_t)bv.integer("byteLength", 0);
-            if (buf < 0 || (size_t)buf >= d.buffers.size() || off + len > d.buffers[buf].size()) return fail_doc(d, "image bufferView exceeds buffer");
+            const int64_t off_i = bv.integer("byteOffset", 0), len_i = bv.integer("byteLength", 0);
+            if (buf < 0 || (size_t)buf >= d.buffers.size() || off_i < 0 || len_i < 0) return fail_doc(d, "image bufferView exceeds buffer");
+            const size_t off = (size_t)off_i, len = (size_t)len_i, have = d.buffers[buf].size();
+            if (off > have || len > have - off) return fail_doc(d, "image bufferView exceeds buffer");
             bytes.assign(d.buffers[buf].begin() + off, d.buffers[buf].begin() + off + len);
             return RTHOST_OK;
         }

@@ -56,6 +56,8 @@ bool decode_hdr(const uint8_t* b, size_t n, std::vector<float>& out, uint32_t& w
         err = "unsupported orientation '" + line + "' (only -Y h +X w)";
         return false;
     }
+    // before anything is allocated: sane dimensions, and at least the 4 bytes a scanline cannot do without
+    if (ww > 65536 || hh > 65536 || (size_t)hh * 4 > n - pos) { err = "resolution line does not fit the file"; return false; }
     w = (uint32_t)ww;
     h = (uint32_t)hh;
     out.assign((size_t)w * h * 4, 1.0f);

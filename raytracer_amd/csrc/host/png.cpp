@@ -54,6 +54,7 @@ bool decode_png(const uint8_t* b, size_t n, std::vector<uint8_t>& out, uint32_t&
         pos += 12 + (size_t)len;
     }
     if (!have_ihdr || w == 0 || h == 0) { err = "missing IHDR"; return false; }
+    if (w > 65535u || h > 65535u) { err = "image larger than 65535 pixels a side (texture sizes are packed in 16 bits, scene.rs:82)"; return false; }
     if (interlace != 0) { err = "interlaced PNG is not supported"; return false; }
     int channels;
     switch (ctype) {

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <limits>
 
 namespace rthost {
@@ -308,14 +310,34 @@ static bool scene_closest_hit(const Scene& s, const float ro_w[3], const float r
 
 using namespace rthost;
 
+// No exception may cross the C ABI: the loaders parse files nobody vouches for, and an allocation
+// they ask for can fail (std::bad_alloc, std::length_error).  Every entry point that allocates runs
+// its body through this.
+template <class F> static int guarded(const char* what, F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        set_error(std::string(what) + ": out of memory");
+        return RTHOST_ERR_LIMIT;
+    } catch (const std::exception& e) {
+        set_error(std::string(what) + ": " + e.what());
+        return RTHOST_ERR_FORMAT;
+    } catch (...) {
+        set_error(std::string(what) + ": unknown failure");
+        return RTHOST_ERR_FORMAT;
+    }
+}
+
 extern "C" {
 
 const char* rthost_last_error(void) { return g_error.c_str(); }
 
 int rthost_scene_new(rthost_scene** out) {
+    return guarded("scene_new", [&]() -> int {
     if (!out) { set_error("scene_new: null out"); return RTHOST_ERR_INVALID; }
     *out = new rthost_scene();
     return RTHOST_OK;
+    });
 }
 void rthost_scene_free(rthost_scene* s) { delete s; }
 
@@ -334,51 +356,64 @@ int rthost_scene_view_get(const rthost_scene* sc, rthost_scene_view* v) {
 }
 
 int rthost_scene_add_texture(rthost_scene* sc, const uint8_t* rgba8, uint32_t w, uint32_t h, uint32_t out_ref[2]) {
+    return guarded("add_texture", [&]() -> int {
     if (!sc || !out_ref) { set_error("add_texture: null argument"); return RTHOST_ERR_INVALID; }
     TexRef r;
     int rc = add_texture(sc->s, rgba8, w, h, &r);
     if (rc == RTHOST_OK) { out_ref[0] = r.offset; out_ref[1] = r.size; }
     return rc;
+    });
 }
 
 int rthost_scene_add_primitive(rthost_scene* sc, const float* positions, uint32_t n_verts, const uint32_t* indices,
                                uint64_t n_indices, const float* normals, const float* uv0, const float* uv1,
                                const uint32_t* colors, const void* material96, const float transform[16],
                                uint32_t* out_prim) {
+    return guarded("add_primitive", [&]() -> int {
     if (!sc || !material96) { set_error("add_primitive: null argument"); return RTHOST_ERR_INVALID; }
     Material m;
     std::memcpy(&m, material96, sizeof m);
     return add_primitive(sc->s, positions, n_verts, indices, n_indices, normals, uv0, uv1, colors, m, transform, out_prim);
+    });
 }
 
 int rthost_scene_add_instance(rthost_scene* sc, uint32_t prim, const float transform[16], uint32_t* out_prim) {
+    return guarded("add_instance", [&]() -> int {
     if (!sc || !transform) { set_error("add_instance: null argument"); return RTHOST_ERR_INVALID; }
     return add_instance(sc->s, prim, transform, out_prim);
+    });
 }
 
 int rthost_scene_set_env(rthost_scene* sc, const float* rgba32f, uint32_t w, uint32_t h) {
+    return guarded("set_env", [&]() -> int {
     if (!sc || !rgba32f || !w || !h) { set_error("set_env: bad argument"); return RTHOST_ERR_INVALID; }
     sc->s.env.assign(rgba32f, rgba32f + (size_t)w * h * 4);
     sc->s.env_w = w;
     sc->s.env_h = h;
     return RTHOST_OK;
+    });
 }
 
 int rthost_scene_load_gltf(rthost_scene* sc, const void* bytes, size_t n, const char* base_dir) {
+    return guarded("load_gltf", [&]() -> int {
     if (!sc || !bytes) { set_error("load_gltf: null argument"); return RTHOST_ERR_INVALID; }
     return load_gltf(sc->s, static_cast<const uint8_t*>(bytes), n, base_dir ? base_dir : ".");
+    });
 }
 
 int rthost_scene_load_gltf_file(rthost_scene* sc, const char* path) {
+    return guarded("load_gltf_file", [&]() -> int {
     if (!sc || !path) { set_error("load_gltf_file: null argument"); return RTHOST_ERR_INVALID; }
     std::vector<uint8_t> bytes;
     if (!read_file(path, bytes)) { set_error(std::string("cannot read ") + path); return RTHOST_ERR_IO; }
     std::string p(path);
     size_t slash = p.find_last_of('/');
     return load_gltf(sc->s, bytes.data(), bytes.size(), slash == std::string::npos ? "." : p.substr(0, slash));
+    });
 }
 
 int rthost_scene_load_hdr_file(rthost_scene* sc, const char* path) {
+    return guarded("load_hdr_file", [&]() -> int {
     if (!sc || !path) { set_error("load_hdr_file: null argument"); return RTHOST_ERR_INVALID; }
     std::vector<uint8_t> bytes;
     if (!read_file(path, bytes)) { set_error(std::string("cannot read ") + path); return RTHOST_ERR_IO; }
@@ -388,6 +423,7 @@ int rthost_scene_load_hdr_file(rthost_scene* sc, const char* path) {
         return RTHOST_ERR_FORMAT;
     }
     return RTHOST_OK;
+    });
 }
 
 void rthost_camera_default(rthost_camera* c) { // input.rs:202-219
@@ -413,9 +449,11 @@ void rthost_camera_to_gpu(const rthost_camera* c, void* out48) { // input.rs:100
 }
 
 int rthost_scene_add_camera(rthost_scene* sc, const rthost_camera* cam) {
+    return guarded("add_camera", [&]() -> int {
     if (!sc || !cam) { set_error("add_camera: null argument"); return RTHOST_ERR_INVALID; }
     sc->s.cameras.push_back(*cam);
     return RTHOST_OK;
+    });
 }
 
 int rthost_scene_get_camera(const rthost_scene* sc, uint32_t idx, rthost_camera* out) {
@@ -459,10 +497,12 @@ int rthost_frame_uniforms(const rthost_scene* sc, uint32_t camera_idx, const voi
 
 int rthost_bvh_build(const void* tris48, uint32_t offset, uint32_t size, void* nodes_out, uint32_t* indices_out,
                      uint32_t* n_nodes_out, int n_threads) {
+    return guarded("bvh_build", [&]() -> int {
     if (!tris48 || !nodes_out || !indices_out || !n_nodes_out) { set_error("bvh_build: null argument"); return RTHOST_ERR_INVALID; }
     if ((uint64_t)offset + size > 0xFFFFFFFFull) { set_error("bvh_build: range overflows u32"); return RTHOST_ERR_LIMIT; }
     *n_nodes_out = bvh_build(static_cast<const float*>(tris48), offset, size, static_cast<Node*>(nodes_out), indices_out, n_threads);
     return RTHOST_OK;
+    });
 }
 
 void rthost_tri_new(const float p1[3], const float p2[3], const float p3[3], void* out48) {

@@ -272,3 +272,42 @@ def test_reference_assets_load_with_expected_shapes(reference_resources):
     m = s.primitives["material"][0]
     np.testing.assert_allclose(m["albedo_factor"], [0.8, 0, 0, 1])
     assert m["metallic_factor"] == 0.0
+
+
+def test_hostile_sizes_are_refused_not_followed(tmp_path):
+    """Counts and offsets a file supplies are checked by subtraction before they are used: a
+    negative or wrapping value is a format error, never an out-of-bounds read, an exception across
+    the C ABI or an attempt to allocate what the file claims."""
+    import json
+    from glb_writer import Glb
+
+    def tampered(edit):
+        g = Glb()
+        pos, nrm, uv, idx = quad()
+        a_pos = g.accessor(pos, "VEC3", 5126)
+        a_idx = g.accessor(idx, "SCALAR", 5123)
+        g.node(mesh=g.mesh([{"attributes": {"POSITION": a_pos}, "indices": a_idx}]))
+        edit(g.doc)
+        return g.tobytes()
+
+    for edit in (lambda d: d["accessors"][0].update(byteOffset=-16),
+                 lambda d: d["accessors"][0].update(count=2 ** 62),
+                 lambda d: d["bufferViews"][0].update(byteOffset=2 ** 63 - 8),
+                 lambda d: d["bufferViews"][0].update(byteStride=2 ** 61),
+                 lambda d: d["accessors"][1].update(count=-3)):
+        s = host.Scene()
+        with pytest.raises(host.RtHostError):
+            s.add_gltf_bytes(tampered(edit))
+
+    # .rtscene header that claims 2^60 triangles
+    p = tmp_path / "bad.rtscene"
+    p.write_bytes(b"RTSCENE1" + struct.pack("<3Q4I", 2 ** 60, 1, 0, 1, 0, 0, 0) + bytes(16) + bytes(64))
+    with pytest.raises(host.RtHostError, match="beyond what a scene can hold|wrong length"):
+        host.Scene.from_cache(str(p))
+
+    # Radiance file whose resolution line promises far more than the file holds
+    q = tmp_path / "bad.hdr"
+    q.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 60000 +X 60000\n" + bytes(64))
+    s = host.Scene()
+    with pytest.raises(host.RtHostError, match="does not fit"):
+        s.set_equirectangular_env_map(str(q))
