@@ -3,6 +3,7 @@
 //   cull        candidate primitives of each ray  (shader.wgsl:603-615; scenes of up to 128 primitives)
 //   extend      closest-hit traversal             (shader.wgsl:598-627, 442-525, 339-438)
 //   shade       miss / kill / BRDF                (shader.wgsl:898-914, 803-885, 941-946)
+//   shadow      sun option: extend's any-hit form + the path's end (shader.wgsl:916-937, 528-575, 630-638)
 //   accumulate  frame-ordered sum into screen     (shader.wgsl:947-951)
 //   resolve     mean + tonemap + sRGB             (shader.wgsl:969-1012; main.rs:116)
 // One launch of extend + shade per bounce for all frames of the group; paths that survive a bounce are compacted into the
@@ -484,7 +485,13 @@ __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi 
 // the first rt_lds_levels() entries; the DEEP instantiation (stack_depth above that, for trees of
 // tens of millions of triangles) continues in a global-memory column per thread, so that a deep
 // stack does not cost occupancy.  The reference does not re-test the box of a popped node either.
-template <bool COUNT, bool DEEP, bool MULTI>
+//
+// ANYHIT instantiation: trace_shadow / trace_bvh_shadow (shader.wgsl:528-575, 630-638) for the
+// shadow rays of the sun option.  The same walk -- primitives in index order, near child first,
+// an overflowing push dropped -- without a distance bound (a box is culled only when the ray misses
+// it), without the alpha test, and over at the first triangle with t >= 0: the ray retires with
+// that triangle in its hit record (-1 = nothing lies along the ray).
+template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false>
 __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
     constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
@@ -857,7 +864,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                     const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
                     if (t >= 0.0f && t < best_t) {
                         bool accept = true;
-                        if (pm >= (1u << RT_PM_MODE_SHIFT)) { // shader.wgsl:464-487
+                        if (!ANYHIT && pm >= (1u << RT_PM_MODE_SHIFT)) { // shader.wgsl:464-487
                             if (COUNT) c_alpha++;
                             const uint32_t mode = pm >> RT_PM_MODE_SHIFT;
                             const PrimX& px = sc.primx[pm & RT_PM_PRIM];
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                                 *sw = seed;
                             }
                         }
-                        if (accept) { best_i = (int32_t)tri_i; best_t = t; }
+                        if (accept) { best_i = (int32_t)tri_i; if (!ANYHIT) best_t = t; }
                     }
                 };
                 test(a0, a1, a2, cur_first);
@@ -891,7 +898,10 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 const uint32_t done = two ? 2u : 1u;
                 cur_first += done;
                 cur_count -= done;
-                if (cur_count == 0u) pop_or_finish();
+                if (ANYHIT && best_i >= 0) { // something lies along the ray: no further node, no further primitive
+                    reinterpret_cast<int32_t*>(a.hits + slot)[1] = best_i;
+                    retire();
+                } else if (cur_count == 0u) pop_or_finish();
             }
 #ifdef RT_PROBE
             if (drained) { pr_n[1]++; pr_t[1] += (uint32_t)(wall_clock64() - pr_mark); }
@@ -910,7 +920,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
                 const uint32_t p = (MULTI ? cb : 0u) + k;
                 const f3 o = F3(ray[0], ray[256], ray[512]), d = F3(ray[768], ray[1024], ray[1280]);
-                const float closest_t = a.hits[slot].x;
+                const float closest_t = ANYHIT ? __builtin_inff() : a.hits[slot].x; // a shadow ray has no distance bound
                 const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
                 const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[3];
                 float4 r1 = pp[4]; // r0, r1: the root node, alpha mode and flags above its count
@@ -1237,82 +1247,26 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
 // ------------------------------------------------------------------ shadow (sun option)
 
 struct ShadowArgs {
-    SceneDev  sc;
     PathQueue in;           // shadow rays written by k_shade<., true>
+    const float4* hits;     // their hit records from the ANYHIT instantiation of k_extend
     const uint32_t* count;
     float4*   partial;
     uint32_t* tap_seed;     // null unless taps are on for this launch
-    uint32_t  stack_depth;
     uint32_t  n_pixels;
     unsigned long long* counters; // null unless counting
 };
 
-// trace_shadow / trace_bvh_shadow, shader.wgsl:528-575, 630-638: does anything lie along the ray?
-// Every primitive in index order until the first triangle with t >= 0; no alpha test, no
-// distance bound, near child first, an overflowing push is dropped.  One lane per shadow ray with
-// a private stack: this is the opt-in path, written for clarity rather than for the last cycle.
-// Primitives whose padded world bound the ray misses are skipped (they cannot occlude).
-// The path then ends: lighting (+ the sun term if nothing occludes) goes to its result slot.
-__global__ __launch_bounds__(256) void k_shadow(ShadowArgs a) {
+// The end of a path that sent a shadow ray towards the sun (shader.wgsl:916-937): lighting, plus
+// the sun term when nothing lies along the ray, goes to the path's result slot.  The traversal
+// itself (trace_shadow) is the ANYHIT instantiation of k_extend.
+__global__ __launch_bounds__(256) void k_shadow_resolve(ShadowArgs a) {
     const uint32_t n = *a.count;
-    const SceneDev& sc = a.sc;
-    const uint32_t depth = min(a.stack_depth, RT_MAX_STACK);
     unsigned long long c_shadow = 0;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
-        const f3 o = F3(s0.x, s0.y, s0.z), d = F3(s0.w, s1.x, s1.y);
+        const float4 s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
         const uint32_t pix = __float_as_uint(s1.w);
+        const bool occluded = __float_as_int(a.hits[slot].y) >= 0;
         c_shadow++;
-        const f3 r = rcp3(d);
-        const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
-        const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
-        bool occluded = false;
-        uint32_t stack[RT_MAX_STACK];
-        for (uint32_t p = 0; p < sc.n_prims && !occluded; p++) {
-            const float* wb = sc.wbounds + (size_t)(p >> 3) * 48u + (p & 7u);
-            const float b[6] = {wb[0], wb[8], wb[16], wb[24], wb[32], wb[40]};
-            if (!overlaps_world_box(oi, idir, b)) continue;
-            const PrimX& px = sc.primx[p];
-            const f3 td = xform_dir(d, px.inv);
-            const f3 ld = td / length(td);
-            const f3 lo = xform_pos(o, px.inv);
-            const f3 lidir = rcp3(ld);
-            const float4* rp = reinterpret_cast<const float4*>(px.root_box);
-            if (hit_aabb_s(lo, lidir, rp[0], rp[1]) < -0.5f) continue;
-            uint32_t first = px.root_first, count = px.root_word & RT_PRIMX_COUNT_MASK, sp = 0;
-            for (;;) {
-                if (count > 0u) {
-                    for (uint32_t i = first; i < first + count && !occluded; i++) {
-                        const float4* tp = rec16(sc.tris, i * 3u);
-                        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                        float u, v;
-                        occluded = hit_tri(lo, ld, F3(a0.x, a0.y, a0.z), F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z), u, v) >= 0.0f;
-                    }
-                    if (occluded || sp == 0u) break;
-                    const float4 q = rec16(sc.nodes, stack[--sp] * 2u)[1];
-                    first = __float_as_uint(q.z);
-                    count = __float_as_uint(q.w);
-                } else {
-                    const float4* np = rec16(sc.nodes, first * 2u);
-                    const float4 l0 = np[0], l1 = np[1], q0 = np[2], q1 = np[3];
-                    const float left = hit_aabb_s(lo, lidir, l0, l1);
-                    const float right = hit_aabb_s(lo, lidir, q0, q1);
-                    const bool lmiss = left < -0.5f, rmiss = right < -0.5f;
-                    if (lmiss && rmiss) {
-                        if (sp == 0u) break;
-                        const float4 q = rec16(sc.nodes, stack[--sp] * 2u)[1];
-                        first = __float_as_uint(q.z);
-                        count = __float_as_uint(q.w);
-                    } else {
-                        const bool go_left = rmiss ? true : (lmiss ? false : left < right);
-                        if (!lmiss && !rmiss && sp < depth) stack[sp++] = go_left ? first + 1u : first;
-                        const float4 c = go_left ? l1 : q1;
-                        first = __float_as_uint(c.z);
-                        count = __float_as_uint(c.w);
-                    }
-                }
-            }
-        }
         f3 lit = F3(s3.x, s3.y, s3.z);
         if (!occluded) lit = lit + F3(s2.x, s2.y, s2.z);
         if (s2.w != 0.0f) lit = F3(1.0f, 1.0f, 0.0f); // a dropped push on the camera path, shader.wgsl:941-943

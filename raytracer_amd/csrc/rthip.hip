@@ -96,9 +96,9 @@ struct rthip_ctx {
     float4*   shadow_mem = nullptr; // sun option: shadow-ray queue (4 planes of queue_cap), allocated on first use
     uint64_t  shadow_cap = 0;
     uint32_t* spill = nullptr;      // deep-stack columns (levels beyond the LDS part), allocated on first use
-    uint64_t  spill_words = 0;    // frames_cap x n_pixels accumulation slots
+    uint64_t  spill_words = 0;
     uint32_t  frames_cap = 0;       // frames one launch group can hold
-    uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors, [128..191] shadow-ray counts
+    uint32_t* ctrl = nullptr;        // [0..63] queue counts per bounce, [64..127] cursors, [128..191] shadow-ray counts, [192..193] ray queries, [256..319] shadow-ray cursors
     int32_t*  tap_tri = nullptr;
     int32_t*  tap_prim = nullptr;
     float*    tap_t = nullptr;
@@ -345,6 +345,11 @@ template <bool COUNT, bool DEEP> void extend_launch_t(bool multi, uint32_t grid,
     if (multi) hipLaunchKernelGGL((k_extend<COUNT, DEEP, true>), dim3(grid), dim3(256), 0, st, ea);
     else hipLaunchKernelGGL((k_extend<COUNT, DEEP, false>), dim3(grid), dim3(256), 0, st, ea);
 }
+// the any-hit form for shadow rays (never counted: the unit of the metric is trace(), not trace_shadow())
+void shadow_extend_launch(bool deep, bool multi, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
+    if (deep) { if (multi) hipLaunchKernelGGL((k_extend<false, true, true, true>), dim3(grid), dim3(256), 0, st, ea); else hipLaunchKernelGGL((k_extend<false, true, false, true>), dim3(grid), dim3(256), 0, st, ea); }
+    else { if (multi) hipLaunchKernelGGL((k_extend<false, false, true, true>), dim3(grid), dim3(256), 0, st, ea); else hipLaunchKernelGGL((k_extend<false, false, false, true>), dim3(grid), dim3(256), 0, st, ea); }
+}
 void extend_launch(bool count, bool deep, bool multi, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
     if (count) { if (deep) extend_launch_t<true, true>(multi, grid, st, ea); else extend_launch_t<true, false>(multi, grid, st, ea); }
     else { if (deep) extend_launch_t<false, true>(multi, grid, st, ea); else extend_launch_t<false, false>(multi, grid, st, ea); }
@@ -381,7 +386,7 @@ int rthip_create(int device_ordinal, rthip_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, RTHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc((void**)&c->ctrl, sizeof(uint32_t) * 256);
+    e = hipMalloc((void**)&c->ctrl, sizeof(uint32_t) * 512);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(Counters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(Counters));
     if (e != hipSuccess) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -863,7 +868,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const uint32_t gen_grid = (uint32_t)((slots + 255) / 256);
         const bool overwrite = (c->reject_hist == 1);
         const bool tap_group = taps && f0 == 0;
-        HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 256, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 512, c->stream));
         ga.out = q[0];
         ga.count_out = c->ctrl;
         ga.first_frame = first_frame + f0 * frame_stride;
@@ -959,17 +964,32 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 }
             }
             if (P.enable_sun) {
+                // trace_shadow for the shadow rays of this bounce: candidate masks, the any-hit walk
+                // (the hit records of this bounce have been consumed by the shade stage), the paths' ends
+                StageTimer t(c, timing, RTHIP_STAGE_SHADOW);
+                ExtArgs xa = ea;
+                xa.in = sa.shadow;
+                xa.count_in = c->ctrl + 128 + b;
+                xa.cursor = c->ctrl + 256 + b;
+                xa.tap = 0u;
+                if (cull) {
+                    CullArgs ca{};
+                    ca.sc = c->sc;
+                    ca.in = sa.shadow;
+                    ca.masks = reinterpret_cast<uint4*>(c->hits);
+                    ca.count_in = xa.count_in;
+                    hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
+                }
+                shadow_extend_launch(deep, multi, ext_grid, c->stream, xa);
                 ShadowArgs wa{};
-                wa.sc = c->sc;
                 wa.in = sa.shadow;
+                wa.hits = c->hits;
                 wa.count = c->ctrl + 128 + b;
                 wa.partial = c->partial;
                 wa.tap_seed = tap_group ? c->tap_seed : nullptr;
-                wa.stack_depth = P.stack_depth;
                 wa.n_pixels = (uint32_t)c->n_pixels;
                 wa.counters = count ? c->d_counters : nullptr;
-                StageTimer t(c, timing, RTHIP_STAGE_SHADOW);
-                hipLaunchKernelGGL(k_shadow, dim3(shade_grid), dim3(256), 0, c->stream, wa);
+                hipLaunchKernelGGL(k_shadow_resolve, dim3(shade_grid), dim3(256), 0, c->stream, wa);
             }
         }
         {

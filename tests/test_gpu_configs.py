@@ -317,3 +317,38 @@ def test_ten_thousand_primitives_use_super_chunks(ctx):
     assert float((got["tri"] == ref["tri"]).mean()) >= 0.999
     hit = (got["tri"] >= 0) & (got["tri"] == ref["tri"])
     assert np.array_equal(got["prim"][hit], ref["prim"][hit])
+
+
+@pytest.mark.parametrize("kind", ["atrium_cull_masks", "instanced_in_kernel_scan", "deep_stack"])
+def test_sun_shadow_rays_on_every_traversal_variant(ctx, atrium, kind):
+    """The sun option's shadow rays (trace_shadow, shader.wgsl:528-575, 630-638: any hit, no alpha
+    test, no distance bound) run on the any-hit form of the extend stage: with candidate masks from
+    the cull stage (103 primitives, MASK materials that shadow rays must treat as opaque), with the
+    in-kernel candidate scan (162 instanced primitives) and with a traversal stack that continues
+    in global memory."""
+    if kind == "atrium_cull_masks":
+        s, a = atrium
+        res, depth = (320, 180), 23
+    elif kind == "instanced_in_kernel_scan":
+        s = procedural.terrain_scene(tiles=9, n=16, env_size=(64, 32), instanced=True)
+        a, res, depth = s.arrays(), (192, 108), 23
+    else:
+        s = procedural.terrain_scene(tiles=6, env_size=(64, 32))
+        a, res, depth = s.arrays(), (192, 108), 40
+    p = device.default_params(max_bounces=4, stack_depth=depth, enable_sun=1)
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=2, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(2, 3, 1, p)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    ref = orc.render(oracle_scene(a), u, oracle_params(p), 2, 3, 1, taps=True, n_threads=THREADS)
+    assert ref["counters"]["shadow_rays"] > 1000
+    assert abs(got["counters"]["shadow_rays"] - ref["counters"]["shadow_rays"]) <= max(4, 2e-3 * ref["counters"]["shadow_rays"])
+    assert got["counters"]["rays"] == pytest.approx(ref["counters"]["rays"], rel=2e-3)   # shadow rays are not counted as rays
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.997
+    same = got["seed"] == ref["seed"]
+    bad = ~np.isclose(got["accum"], ref["accum"], rtol=2e-3, atol=2e-4).all(axis=-1) & same
+    assert bad.mean() <= 2e-4, int(bad.sum())
+    assert np.array_equal(got["accum"][..., 3], ref["accum"][..., 3])
