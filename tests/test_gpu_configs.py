@@ -97,6 +97,33 @@ def test_config3_atrium_1080p_rows_match_oracle(ctx, atrium):
     assert np.all(got["accum"][..., 3] == 2.0)
 
 
+def test_config3_atrium_1080p_whole_frames_match_oracle(ctx, atrium):
+    """Headline workload, every pixel: primary hits and final RNG states of frame 1, and the
+    8-sample image against the oracle's (PSNR in display space; pixels whose paths diverged at a
+    last-ulp branch are in, not masked out)."""
+    s, a = atrium
+    res = (1920, 1080)
+    p = device.default_params(max_bounces=4)
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 8, 1, p)
+    got = dict(accum=ctx.read_accum(), counters=ctx.counters(), **ctx.read_taps())
+    sc = oracle_scene(a)
+    one = orc.render(sc, u, oracle_params(p), 1, 1, 1, taps=True, n_threads=THREADS)
+    assert float((got["tri"] == one["tri"]).mean()) >= 0.9999
+    hit = (got["tri"] == one["tri"]) & (one["tri"] >= 0)
+    assert np.array_equal(got["prim"][hit], one["prim"][hit])
+    assert float((got["seed"] == one["seed"]).mean()) >= 0.999
+    ref = orc.render(sc, u, oracle_params(p), 1, 8, 1, n_threads=THREADS)
+    assert np.all(got["accum"][..., 3] == 8.0) and np.array_equal(ref["accum"][..., 3], got["accum"][..., 3])
+    assert psnr(tonemapped(got["accum"]), tonemapped(ref["accum"])) >= 45.0
+    for k in ("rays", "misses", "kills", "shade_calls", "alpha_tests"):
+        assert abs(got["counters"][k] - ref["counters"][k]) <= 2e-3 * ref["counters"][k], k
+
+
 def test_config3_frame_grouping_is_invisible(ctx, atrium):
     """72 frames in one call (groups of 64 + 8), in groups of 7, and one frame per call give the
     same accumulator bit for bit; so does a second run."""
@@ -352,3 +379,68 @@ def test_sun_shadow_rays_on_every_traversal_variant(ctx, atrium, kind):
     bad = ~np.isclose(got["accum"], ref["accum"], rtol=2e-3, atol=2e-4).all(axis=-1) & same
     assert bad.mean() <= 2e-4, int(bad.sum())
     assert np.array_equal(got["accum"][..., 3], ref["accum"][..., 3])
+
+
+@pytest.mark.timeout(900)
+def test_config5_reference_terrain_tiled_to_fifty_million_triangles(ctx):
+    """Configuration 5 at its named size: the reference's simple_terrain.glb on a 78 x 78 grid merged
+    into one primitive (49.9 M triangles, one BVH from the bit-exact builder), 1920x1080, 16 frames,
+    stack depth 48, seen from above so that the image covers the tiling (the HBM-resident case).
+    Against the oracle where it is affordable -- sampled rows of frame 1 and single rays, bit for
+    bit -- and through size-independent properties: the sample count in the alpha lane, and an
+    accumulator that does not depend on how the 16 frames are grouped."""
+    from util import tiled_reference_terrain
+    s, a = tiled_reference_terrain(78, top_view=True)
+    assert a["tris"].shape[0] == 78 * 78 * 8198 and a["prims"].shape[0] == 1
+    res = (1920, 1080)
+    p = device.default_params(max_bounces=4, stack_depth=48)
+    p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
+    u = s.frame_uniforms(res, frame=1, reject_hist=1, camera_idx=1)
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 16, 1, p)
+    whole = ctx.read_accum()
+    taps = ctx.read_taps()
+    c = ctx.counters()
+    assert np.all(whole[..., 3] == 16.0) and np.isfinite(whole).all()
+    assert c["stack_overflows"] == 0 and c["paths"] == 16 * res[0] * res[1]
+    assert (taps["tri"] >= 0).mean() > 0.4
+    # the same 16 frames in groups of five
+    old = os.environ.get("RTHIP_FRAMES_IN_FLIGHT")
+    try:
+        os.environ["RTHIP_FRAMES_IN_FLIGHT"] = "5"
+        ctx.set_frame_uniforms(u)
+        ctx.render(1, 16, 1, p)
+        assert np.array_equal(whole, ctx.read_accum())
+    finally:
+        if old is None:
+            del os.environ["RTHIP_FRAMES_IN_FLIGHT"]
+        else:
+            os.environ["RTHIP_FRAMES_IN_FLIGHT"] = old
+    # oracle: every 180th row of frame 1, and 300 single rays over the whole extent
+    sc = oracle_scene(a)
+    op = oracle_params(p)
+    ref = orc.render(sc, u, op, 1, 1, 1, taps=True, n_threads=THREADS, row_start=90, row_step=180)
+    rows = np.arange(90, 1080, 180)
+    assert float((taps["tri"][rows] == ref["tri"][rows]).mean()) >= 0.9999
+    same = taps["tri"][rows] == ref["tri"][rows]
+    np.testing.assert_allclose(taps["t"][rows][same], ref["t"][rows][same], rtol=1e-5)
+    rng = np.random.default_rng(17)
+    v = a["tris"]["v"][::997, :, :3].reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    n = 300
+    o = (lo + rng.random((n, 3)) * (hi - lo)).astype(np.float32)
+    o[:, 2] = hi[2] + 5.0
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q = ctx.trace_rays(o, d, None, p)
+    hits = 0
+    for i in range(n):
+        tri, prim, t, _ = orc.trace_ray(sc, o[i], d[i], op, 0)
+        assert q["tri"][i] == tri, i
+        if tri >= 0:
+            hits += 1
+            assert q["t"][i] == np.float32(t), i
+    assert hits > n // 2

@@ -62,3 +62,50 @@ def load_reference_scene(name, env=True):
     else:
         scene.set_env(np.ones((2, 4, 4), np.float32))
     return scene, scene.arrays()
+
+
+def tiled_reference_terrain(tiles, top_view=False):
+    """Configuration 5: the reference's simple_terrain.glb replicated on a tiles x tiles grid, the
+    copies pre-transformed to world space and merged into ONE primitive with ONE BVH (78 x 78 gives
+    49.9 M triangles); tile pitch = the scene's bounding-box extent.  Returns (Scene, arrays).  The
+    first camera is the file's own glTF camera; top_view adds a second one that looks down on the
+    whole tiling."""
+    from raytracer_amd import host
+    base, a = load_reference_scene("simple_terrain", env=False)
+    # world-space vertices of the two primitives' triangles (column-major transform, row vectors)
+    world = []
+    for p in a["prims"]:
+        root = int(p["bvh_idx"])
+        # the triangles of a primitive are the leaves under its root: collect them by walking the tree
+        stack, tri_ids = [root], []
+        nodes = a["nodes"]
+        while stack:
+            n = nodes[stack.pop()]
+            if n["count"] > 0:
+                tri_ids.extend(range(int(n["first"]), int(n["first"]) + int(n["count"])))
+            else:
+                stack += [int(n["first"]), int(n["first"]) + 1]
+        v = a["tris"]["v"][np.array(sorted(tri_ids)), :, :3].astype(np.float64)
+        m = p["transform"].reshape(4, 4).T.astype(np.float64)
+        world.append(v @ m[:3, :3].T + m[:3, 3])
+    tri = np.concatenate(world)                                   # (8198, 3, 3)
+    lo, hi = tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0)
+    pitch = hi - lo
+    ix, iy = np.meshgrid(np.arange(tiles), np.arange(tiles), indexing="ij")
+    offs = np.stack([(ix.ravel() - (tiles - 1) / 2) * pitch[0], (iy.ravel() - (tiles - 1) / 2) * pitch[1], np.zeros(tiles * tiles)], -1)
+    pos = (tri[None].astype(np.float32) + offs[:, None, None, :].astype(np.float32)).reshape(-1, 3)
+    idx = np.arange(pos.shape[0], dtype=np.uint32)
+    # flat shading normals from the geometry
+    e1, e2 = pos[1::3] - pos[0::3], pos[2::3] - pos[0::3]
+    n = np.cross(e1, e2)
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+    nrm = np.repeat(n.astype(np.float32), 3, axis=0)
+    s = host.Scene()
+    s.add_primitive(pos, idx, normals=nrm, material=np.array(a["prims"]["material"][0]))
+    s.add_camera(base.camera(0))
+    if top_view:
+        fovy = np.radians(60.0)
+        height = (tiles * pitch[0] / 2) / (np.tan(fovy / 2) * 16.0 / 9.0)
+        s.add_camera(host.Camera.look((-height * np.tan(np.radians(5.0)), 0.0, hi[2] + height), yaw=0.0, pitch=np.radians(-85.0), fovy=fovy, focus=height))
+    s.set_env(np.ones((2, 4, 4), np.float32) * np.float32(0.7))
+    return s, s.arrays()
