@@ -123,6 +123,8 @@ def workload_key(args):
         k += f"-t{args.tiles}-{args.view}" + ("-inst" if args.instanced else "")
     if args.workload == "atrium" and (args.detail != 1.0 or args.tex != 1024):
         k += f"-d{args.detail}-x{args.tex}"
+    if args.term_prob != 0.5:
+        k += f"-p{args.term_prob}"
     if args.opaque:
         k += "-opaque"
     if args.enable_sun:
