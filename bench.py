@@ -453,6 +453,7 @@ def main():
                 "triangle_layout": "48-byte (p0, e1, e2) records, three 12-byte loads per test (not 9-plane SoA)",
                 "parallelism": (f"spp-split x{n_gpus}" + (" (one process, librthip_group)" if mode == "group" else "")) if n_gpus > 1 else "single",
                 "frames_total": total_frames,
+                "frames_in_flight": ctx.frames_in_flight(),
             },
             "rays_per_step_per_gpu": round(rays_local / local_frames, 1),
             "stage_ms_per_step": {s: round(timing[s]["ms"] / local_frames, 4) for s in ("generate", "cull", "extend", "shade", "shadow", "accumulate")},

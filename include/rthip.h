@@ -142,6 +142,12 @@ int rthip_render(rthip_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32
  * per resolution (main.rs:79-94). */
 int rthip_reserve(rthip_ctx* ctx, uint32_t n_frames);
 
+/* How many frames the next rthip_render would move through the stages together at the current
+ * resolution: RTHIP_FRAMES_IN_FLIGHT (default 64), lowered until the work buffers (160 bytes per
+ * path slot) fit 48 GiB and half of the device memory that is free -- a limit that is otherwise
+ * applied silently.  No counterpart upstream. */
+int rthip_frames_in_flight(rthip_ctx* ctx, uint32_t* n_frames);
+
 /* Use caller-owned DEVICE memory (n_pixels * 4 floats, 16-byte aligned) as the accumulator,
  * e.g. a tensor that a collective library will reduce in place.  NULL returns to a
  * library-owned buffer.  The `screen` storage buffer of shader.wgsl:6. */

@@ -1005,6 +1005,15 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     return RTHIP_OK;
 }
 
+int rthip_frames_in_flight(rthip_ctx* c, uint32_t* n_frames) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!n_frames) return fail(c, RTHIP_ERR_INVALID, "frames_in_flight: null output");
+    if (!c->have_uniforms) return fail(c, RTHIP_ERR_STATE, "frames_in_flight: set_frame_uniforms first (the resolution sizes the buffers)");
+    DeviceGuard g(c->device);
+    *n_frames = frames_in_flight_limit(c);
+    return RTHIP_OK;
+}
+
 int rthip_reserve(rthip_ctx* c, uint32_t n_frames) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!c->have_uniforms) return fail(c, RTHIP_ERR_STATE, "reserve: set_frame_uniforms first (the resolution sizes the buffers)");

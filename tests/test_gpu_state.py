@@ -120,3 +120,20 @@ def test_sixty_four_super_chunks_and_rays_that_meet_none():
         assert hits > n // 8
     finally:
         c.close()
+
+
+def test_frames_in_flight_reports_the_group_size_in_use(monkeypatch):
+    s = procedural.box_scene(env_size=(64, 32))
+    c = device.Context(0)
+    try:
+        c.upload_scene(s.arrays())
+        with pytest.raises(device.RtHipError, match="set_frame_uniforms first"):
+            c.frames_in_flight()
+        c.set_frame_uniforms(s.frame_uniforms((1920, 1080), frame=1, reject_hist=1))
+        assert c.frames_in_flight() == 64
+        c.set_frame_uniforms(s.frame_uniforms((3840, 2160), frame=1, reject_hist=1))
+        assert 16 <= c.frames_in_flight() < 64          # 48 GiB of work buffers at most
+        monkeypatch.setenv("RTHIP_FRAMES_IN_FLIGHT", "7")
+        assert c.frames_in_flight() == 7
+    finally:
+        c.close()
