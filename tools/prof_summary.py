@@ -88,7 +88,8 @@ if bench and ext:
         "source": None,
     }
     if ta is not None:
-        unit, frac = max((("TD (vector-memory data return)", td), ("TA (vector-memory address unit)", ta)), key=lambda x: x[1])
+        # non-idle fractions of the vector-memory units: what the waves wait on, not a throughput utilisation
+        unit, frac = max((("TD (vector-memory data return, non-idle fraction)", td), ("TA (vector-memory address unit, non-idle fraction)", ta)), key=lambda x: x[1])
         entry["limiter_unit"], entry["limiter_busy_frac"] = unit, round(frac, 4)
     for name, (n, total) in kernel_ns.items():
         if name.startswith("void k_extend<false") and n:
