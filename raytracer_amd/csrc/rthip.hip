@@ -11,7 +11,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
-#include <map>
 #include <string>
 #include <vector>
 
@@ -91,7 +90,8 @@ struct rthip_ctx {
     // host copy of the device tree, for the precomputed walk of a NaN-direction ray
     std::vector<HostNode> host_nodes;
     std::vector<uint32_t> prim_roots;
-    std::map<uint32_t, NanWalk> nan_walks; // by stack depth
+    NanWalk   nan_walks[RT_MAX_STACK + 1]; // by stack depth; filled on first use (no heap: the no-alloc entry point uses it too)
+    bool      nan_walk_valid[RT_MAX_STACK + 1] = {};
     float4*   partial = nullptr;
     float4*   shadow_mem = nullptr; // sun option: shadow-ray queue (4 planes of queue_cap), allocated on first use
     uint64_t  shadow_cap = 0;
@@ -423,10 +423,10 @@ int rthip_set_stream(rthip_ctx* c, void* hip_stream) {
 // Walks the device tree the way a NaN-direction ray does, with a stack of `depth` entries whose
 // overflowing pushes are dropped (shader.wgsl:306-313), and counts the steps.
 static const NanWalk& nan_walk(rthip_ctx* c, uint32_t depth) {
-    auto it = c->nan_walks.find(depth);
-    if (it != c->nan_walks.end()) return it->second;
+    depth = std::min<uint32_t>(depth, RT_MAX_STACK);
+    if (c->nan_walk_valid[depth]) return c->nan_walks[depth];
     NanWalk w;
-    std::vector<uint32_t> stack(depth ? depth : 1);
+    uint32_t stack[RT_MAX_STACK + 1];
     for (uint32_t root : c->prim_roots) {
         uint32_t sp = 0;
         uint32_t first = c->host_nodes[root].first, count = c->host_nodes[root].count;
@@ -448,7 +448,9 @@ static const NanWalk& nan_walk(rthip_ctx* c, uint32_t depth) {
             }
         }
     }
-    return c->nan_walks.emplace(depth, w).first->second;
+    c->nan_walks[depth] = w;
+    c->nan_walk_valid[depth] = true;
+    return c->nan_walks[depth];
 }
 
 int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
@@ -710,7 +712,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->prim_roots.resize(s->n_prims);
     for (uint32_t p = 0; p < s->n_prims; p++) c->prim_roots[p] = primx[p].root;
     c->host_nodes.swap(dev_nodes);
-    c->nan_walks.clear();
+    for (bool& v : c->nan_walk_valid) v = false;
     (void)nan_walk(c, 23); // the default stack depth; other depths are walked at their first render
     c->node_index_map.swap(map);
     c->have_scene = true;
