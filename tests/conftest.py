@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# PyTorch brings its own copy of the HIP and HSA runtimes; librthip.so links ROCm's.  Whichever
+# runtime opens the GPU first keeps it: torch loaded after a device context exists reports "No HIP
+# GPUs are available".  Loaded first, both share torch's copy (same soname).  Several GPU tests hand
+# torch tensors to the library, so torch is imported before any test can load the library.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
