@@ -80,3 +80,12 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "rt_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_rust_ffi_crate_declares_every_c_entry_point():
+    """rust/rthip-sys cannot be compiled here (no cargo); at least its extern blocks must name
+    exactly the functions the two headers declare, so that it does not drift from the ABI."""
+    src = open(os.path.join(ROOT, "rust", "rthip-sys", "src", "lib.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (rthip_\w+)\s*\(", src)))
+    want = sorted(set(declared("rthip.h", "rthip")) | set(declared("rthip_group.h", "rthip_group")))
+    assert rust == want, (sorted(set(want) - set(rust)), sorted(set(rust) - set(want)))
