@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--terrain-n", type=int, default=60)
     ap.add_argument("--view", default="ground", choices=("ground", "top"), help="terrain camera: near the first tiles, or looking down on the whole tiling")
     ap.add_argument("--instanced", action="store_true", help="terrain tiles as instanced primitives instead of one merged BVH")
+    ap.add_argument("--shuffled", action="store_true", help="instanced terrain: list the instances in random order")
     ap.add_argument("--enable-sun", action="store_true", help="the sun option (shadow rays); not the reference's live behaviour")
     ap.add_argument("--random-rays", type=int, default=0, help="also time this many uniformly random rays over the scene's extent through rthip_trace_rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +121,7 @@ def workload_key(args):
         return "scene:" + os.path.basename(args.scene)
     k = f"{args.workload}-{args.res}-b{args.max_bounces}"
     if args.workload == "terrain":
-        k += f"-t{args.tiles}-{args.view}" + ("-inst" if args.instanced else "")
+        k += f"-t{args.tiles}-{args.view}" + ("-inst" if args.instanced else "") + ("-shuf" if args.shuffled else "")
     if args.workload == "atrium" and (args.detail != 1.0 or args.tex != 1024):
         k += f"-d{args.detail}-x{args.tex}"
     if args.term_prob != 0.5:
@@ -157,8 +158,8 @@ def build_workload(args):
         scene = procedural.blob_scene()
         name = "suzanne-proxy blob"
     elif args.workload == "terrain":
-        scene = procedural.terrain_scene(tiles=args.tiles, n=args.terrain_n, instanced=args.instanced, view=args.view)
-        name = f"terrain tiled {args.tiles}x{args.tiles}" + (" as instances" if args.instanced else "") + f", {args.view} view"
+        scene = procedural.terrain_scene(tiles=args.tiles, n=args.terrain_n, instanced=args.instanced, view=args.view, shuffled=args.shuffled)
+        name = f"terrain tiled {args.tiles}x{args.tiles}" + (" as instances" if args.instanced else "") + (" in shuffled order" if args.shuffled else "") + f", {args.view} view"
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     return scene, name
@@ -454,6 +455,7 @@ def main():
                 "parallelism": (f"spp-split x{n_gpus}" + (" (one process, librthip_group)" if mode == "group" else "")) if n_gpus > 1 else "single",
                 "frames_total": total_frames,
                 "frames_in_flight": ctx.frames_in_flight(),
+                "candidate_walk": ctx.candidate_walk(),
             },
             "rays_per_step_per_gpu": round(rays_local / local_frames, 1),
             "stage_ms_per_step": {s: round(timing[s]["ms"] / local_frames, 4) for s in ("generate", "cull", "extend", "shade", "shadow", "accumulate")},

@@ -169,6 +169,10 @@ struct ExtArgs {
     unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped;
     uint32_t  nan_overflow;
     uint32_t  pad2;
+    // TREE instantiation only (scenes of more than 8192 primitives): the pyramid of union bounds
+    // over the primitives in index order, and its directory
+    const float4*   tlas;      // records of 192 bytes: the padded world bounds of eight consecutive entities of one level, [6 planes][8]
+    const uint32_t* tlas_dir;  // [0] = top level T; [1 + L] = first record of level L; [1 + RT_TLAS_MAX_LEVELS + L] = entities at level L
 #ifdef RT_PROBE
     unsigned long long* probe; // diagnostic build: per wave (start, queue seen empty, end) in 100 MHz ticks and the most steps one of its rays took
 #endif
@@ -193,6 +197,7 @@ __device__ __forceinline__ bool overlaps_world_box(f3 oi, f3 idir, const float (
 #define ST_INNER 1u   // at an inner node: test the two children (shader.wgsl:496-521)
 #define ST_LEAF  2u   // inside a leaf: test one triangle per step (shader.wgsl:458-495)
 #define ST_SCAN  3u   // has a ray, needs the candidate mask of primitives [cb, cb + 128)
+#define ST_TLAS  6u   // TREE: stands at a record of the bounds pyramid that it has not tested yet
 #define ST_DONE  4u   // its ray is finished and written back: wants a new one
 #define ST_IDLE  5u   // the queue is drained: nothing more to do
 
@@ -491,9 +496,26 @@ __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi 
 // an overflowing push dropped -- without a distance bound (a box is culled only when the ray misses
 // it), without the alpha test, and over at the first triangle with t >= 0: the ray retires with
 // that triangle in its hit record (-1 = nothing lies along the ray).
-template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false>
+//
+// TREE instantiation (with MULTI; scenes of more than 8192 primitives, where the chunk scan grows
+// linearly): the candidates come from a walk of an implicit 8-ary pyramid over the primitives IN
+// INDEX ORDER instead.  Level 0 are the primitives, an entity of level L + 1 is the union bound of
+// eight consecutive entities of level L, the top level has at most eight.  A lane walks it depth
+// first, children in ascending order, so the primitives whose padded bounds its ray meets come out
+// in the reference's index order; its whole walk state is one dword (level, record) and one byte
+// of pending children per level.  One step tests the eight bounds of a record (twelve 16-byte
+// loads); steps are a fourth kind of round in the vote.
+#define RT_TLAS_MAX_LEVELS 8u   // 8^8 = 16.7 M primitives; a scene of more keeps the chunk scan
+template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false, bool TREE = false>
 __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
+    static_assert(!TREE || MULTI, "TREE is a variant of MULTI");
+    constexpr bool SCAN = MULTI && !TREE;
     constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
+    __shared__ uint32_t lds_tlas_dir[1 + 2 * RT_TLAS_MAX_LEVELS];
+    if (TREE) {
+        if (threadIdx.x < 1u + 2u * RT_TLAS_MAX_LEVELS) lds_tlas_dir[threadIdx.x] = a.tlas_dir[threadIdx.x];
+        __syncthreads();
+    }
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
     // world-space origin and direction of each lane's ray, read again at every primitive it enters
     __shared__ float lds_ray[6 * 256];
@@ -533,7 +555,9 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
     uint32_t st = ST_DONE;
     uint32_t slot = 0;
     uint32_t mask[4] = {0, 0, 0, 0};
-    uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes (MULTI)
+    uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes (MULTI); TREE: the next candidate primitive
+    uint32_t tl = 0;                  // TREE: level << 28 | record of the pyramid the lane stands at
+    unsigned long long tl_pending = 0; // TREE: byte L = children of the lane's record at level L still to visit
     unsigned long long cmask = ~0ull; // bit c: the ray meets the union bound of chunk c (c < 64)
     uint32_t pm = 0; // RT_PM_PRIM: current primitive; RT_PM_OVERFLOW: a push of this ray was dropped; top bits: alpha mode
     uint32_t cur_first = 0, cur_count = 0, sp = 0;
@@ -558,12 +582,32 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
     };
     // between primitives: next candidate of this chunk, else the next chunk, else the ray is done
     auto advance = [&]() {
-        if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) {
+        if (TREE) {
+            // the next pending child, in ascending order: a primitive (level 0), a record to descend
+            // into, or, when the top record is used up, the end of the ray
+            const uint32_t top = lds_tlas_dir[0];
+            for (;;) {
+                const uint32_t lvl = tl >> 28, rec = tl & 0x0FFFFFFFu;
+                const uint32_t pend = (uint32_t)(tl_pending >> (8u * lvl)) & 0xFFu;
+                if (pend == 0u) {
+                    if (lvl >= top) { retire(); break; }
+                    tl = ((lvl + 1u) << 28) | (rec >> 3);
+                    continue;
+                }
+                const uint32_t k = (uint32_t)__builtin_ctz(pend);
+                tl_pending &= ~(1ull << (8u * lvl + k));
+                const uint32_t ent = rec * 8u + k;
+                if (lvl == 0u) { cb = ent; st = ST_PRIM; break; }
+                tl = ((lvl - 1u) << 28) | ent;
+                st = ST_TLAS;
+                break;
+            }
+        } else if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) {
             st = ST_PRIM;
         } else {
             // the next chunk: the one that follows inside the same super-chunk, else the first of
             // the next super-chunk whose union bound the ray meets (cmask)
-            if (MULTI) {
+            if (SCAN) {
                 uint32_t next = (cb >> 7) + 1u;
                 const uint32_t sh = sc.chunk_shift;
                 if ((next & ((1u << sh) - 1u)) == 0u) {
@@ -624,7 +668,8 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
         const unsigned long long scan_m = __ballot(st == ST_SCAN);
         const unsigned long long done_m = __ballot(st == ST_DONE);
         const uint32_t n_scan = (uint32_t)__popcll(scan_m), n_done = (uint32_t)__popcll(done_m);
-        const uint32_t n_trav = n_prim + n_inner + n_leaf;
+        const uint32_t n_tlas = TREE ? (uint32_t)__popcll(__ballot(st == ST_TLAS)) : 0u;
+        const uint32_t n_trav = n_prim + n_inner + n_leaf + n_tlas;
 
         // ---- refill: hand reserved queue slots to the lanes that wait for a ray
         if (n_done != 0u && !drained && (n_done >= RT_REFILL_LANES || n_trav + n_scan == 0u)) {
@@ -673,8 +718,9 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                         ray[768] = d.x; ray[1024] = d.y; ray[1280] = d.z;
                         pm = 0;
                         cb = 0;
-                        if (MULTI) cmask = ~0ull;
+                        if (SCAN) cmask = ~0ull;
                         st = ST_SCAN;
+                        if (TREE) { tl = lds_tlas_dir[0] << 28; tl_pending = 0ull; st = ST_TLAS; } // at the top record, untested
                         fresh = true;
 #ifdef RT_PROBE
                         pr_max = max(pr_max, pr_steps);
@@ -704,7 +750,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 run_next += min(avail, n_done);
                 // scenes of more than one chunk: which (super-)chunks can the new rays touch at all
                 // (wave-uniform over their union bounds, scalar loads)
-                if (MULTI) {
+                if (SCAN) {
                     const f3 r = rcp3(d);
                     const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
                     const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
@@ -731,7 +777,7 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
         }
 
         // ---- candidate scan for the lanes that wait for a mask (wave-uniform over primitives)
-        if (MULTI && n_scan != 0u && (n_scan >= RT_SCAN_LANES || n_trav == 0u)) {
+        if (SCAN && n_scan != 0u && (n_scan >= RT_SCAN_LANES || n_trav == 0u)) {
             // the chunk the first waiting lane wants; lanes that want another chunk wait for a later scan
             const uint32_t c0 = MULTI ? __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(scan_m)) : 0u;
             const bool mine = st == ST_SCAN && (!MULTI || cb == c0);
@@ -804,7 +850,35 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
 #ifdef RT_PROBE
         pr_mark = wall_clock64();
 #endif
-        if (n_inner >= n_prim && n_inner >= n_leaf) {
+        if (TREE && n_tlas != 0u && n_tlas >= n_inner && n_tlas >= n_leaf && n_tlas >= n_prim) {
+            if (st == ST_TLAS) {
+                // which of the eight entities of the lane's record does the ray meet (padded world
+                // bounds: conservative, like the candidate masks of the other instantiations)
+                const f3 o = F3(ray[0], ray[256], ray[512]);
+                const f3 r = rcp3(F3(ray[768], ray[1024], ray[1280])); // clamped like the scan's, see there
+                const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
+                const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
+                const uint32_t lvl = tl >> 28, rec = tl & 0x0FFFFFFFu;
+                const float4* rp = rec16(a.tlas, (lds_tlas_dir[1u + lvl] + rec) * 12u);
+                uint32_t m = 0;
+#pragma unroll 1
+                for (int half = 0; half < 2; half++) { // four entities at a time: six loads in flight, not twelve
+                    const float4 lx = rp[0 + half], ly = rp[2 + half], lz = rp[4 + half];
+                    const float4 hx = rp[6 + half], hy = rp[8 + half], hz = rp[10 + half];
+                    const float b0[6] = {lx.x, ly.x, lz.x, hx.x, hy.x, hz.x}, b1[6] = {lx.y, ly.y, lz.y, hx.y, hy.y, hz.y};
+                    const float b2[6] = {lx.z, ly.z, lz.z, hx.z, hy.z, hz.z}, b3[6] = {lx.w, ly.w, lz.w, hx.w, hy.w, hz.w};
+                    m |= (overlaps_world_box(oi, idir, b0) ? 1u : 0u) << (4 * half);
+                    m |= (overlaps_world_box(oi, idir, b1) ? 2u : 0u) << (4 * half);
+                    m |= (overlaps_world_box(oi, idir, b2) ? 4u : 0u) << (4 * half);
+                    m |= (overlaps_world_box(oi, idir, b3) ? 8u : 0u) << (4 * half);
+                }
+                // the last record of a level is padded to eight: drop what does not exist
+                const uint32_t have = lds_tlas_dir[1u + RT_TLAS_MAX_LEVELS + lvl] - rec * 8u;
+                if (have < 8u) m &= (1u << have) - 1u;
+                tl_pending = (tl_pending & ~(0xFFull << (8u * lvl))) | ((unsigned long long)m << (8u * lvl));
+                advance();
+            }
+        } else if (n_inner >= n_prim && n_inner >= n_leaf) {
 #pragma unroll 1
             for (int burst = 0; burst < RT_INNER_BURST; burst++) {
                 if (COUNT) r_inner++;
@@ -913,11 +987,13 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                 pr_steps++;
 #endif
                 // next candidate in index order
-                uint32_t k;
-                if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
-                else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
-                else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
-                else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
+                uint32_t k = 0;
+                if (!TREE) {
+                    if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
+                    else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
+                    else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
+                    else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
+                }
                 const uint32_t p = (MULTI ? cb : 0u) + k;
                 const f3 o = F3(ray[0], ray[256], ray[512]), d = F3(ray[768], ray[1024], ray[1280]);
                 const float closest_t = ANYHIT ? __builtin_inff() : a.hits[slot].x; // a shadow ray has no distance bound

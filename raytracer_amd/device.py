@@ -26,7 +26,7 @@ EXPORTS = (
     "rthip_read_tri_order", "rthip_read_tris_device_layout", "rthip_resolve",
     "rthip_get_counters", "rthip_reset_counters", "rthip_get_timing", "rthip_reset_timing",
     "rthip_synchronize", "rthip_copy_bandwidth", "rthip_trace_rays", "rthip_trace_rays_noalloc",
-    "rthip_frames_in_flight",
+    "rthip_frames_in_flight", "rthip_candidate_walk",
 )
 
 
@@ -90,6 +90,7 @@ def lib():
         l.rthip_default_params.argtypes = [C.POINTER(RenderParams)]
         l.rthip_reserve.argtypes = [vp, C.c_uint32]
         l.rthip_frames_in_flight.argtypes = [vp, C.POINTER(C.c_uint32)]
+        l.rthip_candidate_walk.argtypes = [vp, C.POINTER(C.c_uint32)]
         l.rthip_trace_rays.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_trace_rays_noalloc.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_copy_bandwidth.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
@@ -227,6 +228,12 @@ class Context:
         n = C.c_uint32()
         self._check(lib().rthip_frames_in_flight(self._h, C.byref(n)))
         return int(n.value)
+
+    def candidate_walk(self):
+        """How the uploaded scene's primitives are enumerated per ray: "mask", "scan" or "pyramid"."""
+        k = C.c_uint32()
+        self._check(lib().rthip_candidate_walk(self._h, C.byref(k)))
+        return ("mask", "scan", "pyramid")[k.value]
 
     def copy_bandwidth(self, nbytes=1 << 30, repeats=8):
         """Device-to-device stream-copy ceiling in GB/s (read + write traffic)."""

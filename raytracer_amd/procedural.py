@@ -346,14 +346,16 @@ def terrain_mesh(n=60, size=40.0, seed=7):
     return grid(n, n, (size, size), height=height, uv_scale=8.0)
 
 
-def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False, view="ground"):
+def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False, view="ground", shuffled=False):
     """Stand-in for resources/simple_terrain.glb (a ~7 k-triangle plane plus a ~1 k-triangle
     object, own camera) and, with tiles > 1, for its tiling into one large primitive
     (tiles^2 copies merged into one BVH): the HBM-resident traversal stress case.  With
     instanced=True the tiles stay 2 * tiles^2 primitives that share two BVHs: the stress case
     for the number of primitives.  view="ground" is the glTF-style camera near the first tiles
     (it sees a sliver of a large tiling); view="top" looks down on the whole tiling from a height at
-    which the image is as wide as the terrain, so that every pixel lands in another part of it."""
+    which the image is as wide as the terrain, so that every pixel lands in another part of it.
+    shuffled=True lists the instances in random instead of row-major order: neighbours in the
+    primitive list are then no neighbours in space (the worst case for bounds over index ranges)."""
     size = 40.0
     t = terrain_mesh(n, size)
     rock = uv_sphere(22, 23, radius=2.0)  # 968 triangles
@@ -367,11 +369,12 @@ def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False, view="gr
         pos = lambda i, j, z: host.trs(((i - tiles / 2 + 0.5) * size, (j - tiles / 2 + 0.5) * size, z))
         pt = s.add_primitive(t[0], t[1], normals=t[2], uv0=t[3], material=mat, transform=pos(0, 0, 0.0))
         pr = s.add_primitive(rock[0], rock[1], normals=rock[2], uv0=rock[3], material=mat, transform=pos(0, 0, 2.5))
-        for i in range(tiles):
-            for j in range(tiles):
-                if i or j:
-                    s.add_instance(pt, pos(i, j, 0.0))
-                    s.add_instance(pr, pos(i, j, 2.5))
+        cells = [(i, j) for i in range(tiles) for j in range(tiles) if i or j]
+        if shuffled:
+            cells = [cells[k] for k in np.random.default_rng(tiles).permutation(len(cells))]
+        for i, j in cells:
+            s.add_instance(pt, pos(i, j, 0.0))
+            s.add_instance(pr, pos(i, j, 2.5))
     else:
         parts = []
         for i in range(tiles):

@@ -137,3 +137,97 @@ def test_frames_in_flight_reports_the_group_size_in_use(monkeypatch):
         assert c.frames_in_flight() == 7
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("tiles,n_mesh", [(9, 8), (16, 8), (33, 4)])
+def test_bounds_pyramid_walk_equals_chunk_scan(monkeypatch, tiles, n_mesh):
+    """Scenes of many primitives take their candidates from a walk of an 8-ary pyramid of union
+    bounds instead of the chunk scan.  Forced on for small scenes (162, 512 and 2178 primitives: three and
+    four levels, full and ragged last records), it must give the same image, taps and traversal counters as
+    the scan, and ray queries equal to the oracle's."""
+    s = procedural.terrain_scene(tiles=tiles, n=n_mesh, env_size=(64, 32), instanced=True)
+    a = s.arrays()
+    assert a["prims"].shape[0] == 2 * tiles * tiles
+    res = (160, 96)
+    p = device.default_params()
+    p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
+
+    def run(tree):
+        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "8" if tree else "4000000000")
+        c = device.Context(0)
+        try:
+            c.upload_scene(a)
+            assert c.candidate_walk() == ("pyramid" if tree else "scan")
+            c.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+            c.reset_counters()
+            c.render(1, 3, 1, p)
+            out = dict(accum=c.read_accum(), counters=c.counters(), **c.read_taps())
+            rng = np.random.default_rng(11)
+            n = 192
+            ext = 20.0 * tiles
+            o = np.column_stack([rng.uniform(-ext, ext, n), rng.uniform(-ext, ext, n), rng.uniform(0.5, 30, n)]).astype(np.float32)
+            d = rng.normal(size=(n, 3)).astype(np.float32)
+            d[:, 2] -= 0.3
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            out["q"] = c.trace_rays(o, d)
+            out["rays"] = (o, d)
+            return out
+        finally:
+            c.close()
+
+    scan, tree = run(False), run(True)
+    assert np.array_equal(scan["accum"], tree["accum"])
+    for k in ("tri", "prim", "t", "seed"):
+        assert np.array_equal(scan[k], tree[k]), k
+    for k in ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "shade_calls", "misses", "kills", "stack_overflows", "paths"):
+        assert scan["counters"][k] == tree["counters"][k], k
+    sc = oracle_scene(a)
+    op = oracle_params(device.default_params())
+    o, d = tree["rays"]
+    hits = 0
+    for i in range(len(o)):
+        tri, prim, t, _ = orc.trace_ray(sc, o[i], d[i], op, 0)
+        assert tree["q"]["tri"][i] == tri, i
+        if tri >= 0:
+            hits += 1
+            assert tree["q"]["prim"][i] == prim and tree["q"]["t"][i] == np.float32(t), i
+    assert hits > len(o) // 8
+
+
+def test_pyramid_only_for_long_lists_in_coherent_order(monkeypatch):
+    """Row-major tiles: consecutive primitives are neighbours, bounds over index ranges are tight.
+    The same instances in shuffled order: every range spans the scene and the chunk scan is kept.
+    Either way the image is the same as the other walk's (the order of the list differs between the
+    two scenes, so each is compared with itself)."""
+    monkeypatch.delenv("RTHIP_TREE_MIN_PRIMS", raising=False)
+    kinds = {}
+    for shuffled in (False, True):
+        s = procedural.terrain_scene(tiles=32, n=4, env_size=(64, 32), instanced=True, shuffled=shuffled)
+        a = s.arrays()
+        assert a["prims"].shape[0] == 2048
+        c = device.Context(0)
+        try:
+            c.upload_scene(a)
+            kinds[shuffled] = c.candidate_walk()
+            c.set_frame_uniforms(s.frame_uniforms((96, 64), frame=1, reject_hist=1))
+            c.render(1, 2, 1, device.default_params())
+            own = c.read_accum()
+            monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000" if kinds[shuffled] == "pyramid" else "8")
+            c.upload_scene(a)
+            assert c.candidate_walk() != kinds[shuffled]
+            c.set_frame_uniforms(s.frame_uniforms((96, 64), frame=1, reject_hist=1))
+            c.render(1, 2, 1, device.default_params())
+            assert np.array_equal(own, c.read_accum())
+            monkeypatch.delenv("RTHIP_TREE_MIN_PRIMS")
+        finally:
+            c.close()
+    assert kinds == {False: "pyramid", True: "scan"}
+    small = procedural.box_scene(env_size=(64, 32))
+    c = device.Context(0)
+    try:
+        with pytest.raises(device.RtHipError, match="no scene"):
+            c.candidate_walk()
+        c.upload_scene(small.arrays())
+        assert c.candidate_walk() == "mask"
+    finally:
+        c.close()
