@@ -657,7 +657,12 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
             finish();
         } else {
             --sp;
-            enter_desc((DEEP && sp >= RT_LDS_LEVELS) ? spill_at(sp) : stack[sp * RT_WAVE]);
+            // two separate loads (a plain select of the two addresses compiles to one flat load, which
+            // takes the vector-memory path for LDS addresses too); a spilled level is read once
+            uint32_t e;
+            if (DEEP && sp >= RT_LDS_LEVELS) e = *const_cast<volatile uint32_t*>(&spill_at(sp));
+            else e = stack[sp * RT_WAVE];
+            enter_desc(e);
         }
     };
 
@@ -889,10 +894,28 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
 #endif
                     // the sibling pair: 48 bytes of boxes and a descriptor dword per child
                     const float4* np = rec16(sc.pairs, cur_first * 2u);
+#ifdef RT_DIAG_EXTRA_LOADS
+                    // Diagnostic build: RT_DIAG_EXTRA_LOADS further dword loads per inner-node step, from the
+                    // line the step reads anyway (or, with RT_DIAG_UNIFORM, from one address for the whole
+                    // wave), issued ahead of the step's own loads: loads return in order, so the step's waits
+                    // cover them.  What the stage's time does with them tells what a load costs it.
+                    float xv[RT_DIAG_EXTRA_LOADS];
+#pragma unroll
+                    for (int x = 0; x < RT_DIAG_EXTRA_LOADS; x++)
+#ifdef RT_DIAG_UNIFORM
+                        asm volatile("global_load_dword %0, %1, off offset:60" : "=v"(xv[x]) : "v"(sc.pairs) : "memory");
+#else
+                        asm volatile("global_load_dword %0, %1, off offset:60" : "=v"(xv[x]) : "v"(np) : "memory");
+#endif
+#endif
                     const float4 b0 = np[0], b1 = np[1], b2 = np[2];
                     const uint2 dsc = *reinterpret_cast<const uint2*>(np + 3);
                     const float left = hit_aabb6(lo, lidir, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
                     const float right = hit_aabb6(lo, lidir, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w);
+#ifdef RT_DIAG_EXTRA_LOADS
+#pragma unroll
+                    for (int x = 0; x < RT_DIAG_EXTRA_LOADS; x++) asm volatile("" :: "v"(xv[x])); // keeps the registers until here
+#endif
                     const bool lmiss = (left < -0.5f || left > best_t);
                     const bool rmiss = (right < -0.5f || right > best_t);
                     if (lmiss && rmiss) {

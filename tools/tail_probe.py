@@ -20,7 +20,7 @@ LIB = os.path.join(ROOT, "raytracer_amd", "lib", "librthip_probe.so")
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     src = os.path.join(ROOT, "raytracer_amd", "csrc", "rthip.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                            "-DRT_PROBE", "-o", LIB, src])
 
 
