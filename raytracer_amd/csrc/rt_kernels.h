@@ -169,7 +169,7 @@ struct ExtArgs {
     unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped;
     uint32_t  nan_overflow;
     uint32_t  pad2;
-    // TREE instantiation only (scenes of more than 8192 primitives): the pyramid of union bounds
+    // TREE instantiation only (long primitive lists): the pyramid of union bounds
     // over the primitives in index order, and its directory
     const float4*   tlas;      // records of 192 bytes: the padded world bounds of eight consecutive entities of one level, [6 planes][8]
     const uint32_t* tlas_dir;  // [0] = top level T; [1 + L] = first record of level L; [1 + RT_TLAS_MAX_LEVELS + L] = entities at level L
@@ -458,6 +458,9 @@ __device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, fl
 #define RT_EXTEND_WAVES_SINGLE 8
 #endif
 #define RT_EXTEND_WAVES_MULTI 7
+#ifndef RT_EXTEND_WAVES_TREE
+#define RT_EXTEND_WAVES_TREE 7
+#endif
 __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi ? RT_LDS_LEVELS_MULTI : RT_LDS_LEVELS_SINGLE; }
 #define RT_MAX_STACK 64u
 
@@ -497,8 +500,8 @@ __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi 
 // it), without the alpha test, and over at the first triangle with t >= 0: the ray retires with
 // that triangle in its hit record (-1 = nothing lies along the ray).
 //
-// TREE instantiation (with MULTI; scenes of more than 8192 primitives, where the chunk scan grows
-// linearly): the candidates come from a walk of an implicit 8-ary pyramid over the primitives IN
+// TREE instantiation (with MULTI; long primitive lists whose neighbours are neighbours in space,
+// where the chunk scan grows linearly): the candidates come from a walk of an implicit 8-ary pyramid over the primitives IN
 // INDEX ORDER instead.  Level 0 are the primitives, an entity of level L + 1 is the union bound of
 // eight consecutive entities of level L, the top level has at most eight.  A lane walks it depth
 // first, children in ascending order, so the primitives whose padded bounds its ray meets come out
@@ -507,7 +510,7 @@ __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi 
 // loads); steps are a fourth kind of round in the vote.
 #define RT_TLAS_MAX_LEVELS 8u   // 8^8 = 16.7 M primitives; a scene of more keeps the chunk scan
 template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false, bool TREE = false>
-__global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
+__global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
     static_assert(!TREE || MULTI, "TREE is a variant of MULTI");
     constexpr bool SCAN = MULTI && !TREE;
     constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
@@ -899,14 +902,20 @@ __global__ __launch_bounds__(256, MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVE
                     // line the step reads anyway (or, with RT_DIAG_UNIFORM, from one address for the whole
                     // wave), issued ahead of the step's own loads: loads return in order, so the step's waits
                     // cover them.  What the stage's time does with them tells what a load costs it.
+                    // RT_DIAG_WIDE makes them 16-byte loads.
+#if defined(RT_DIAG_WIDE)
+                    typedef float rt_diag4 __attribute__((ext_vector_type(4)));
+                    rt_diag4 xv[RT_DIAG_EXTRA_LOADS];
+#define RT_DIAG_LOAD(dst) asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(dst) : "v"(np) : "memory")
+#elif defined(RT_DIAG_UNIFORM)
                     float xv[RT_DIAG_EXTRA_LOADS];
-#pragma unroll
-                    for (int x = 0; x < RT_DIAG_EXTRA_LOADS; x++)
-#ifdef RT_DIAG_UNIFORM
-                        asm volatile("global_load_dword %0, %1, off offset:60" : "=v"(xv[x]) : "v"(sc.pairs) : "memory");
+#define RT_DIAG_LOAD(dst) asm volatile("global_load_dword %0, %1, off offset:60" : "=v"(dst) : "v"(sc.pairs) : "memory")
 #else
-                        asm volatile("global_load_dword %0, %1, off offset:60" : "=v"(xv[x]) : "v"(np) : "memory");
+                    float xv[RT_DIAG_EXTRA_LOADS];
+#define RT_DIAG_LOAD(dst) asm volatile("global_load_dword %0, %1, off offset:60" : "=v"(dst) : "v"(np) : "memory")
 #endif
+#pragma unroll
+                    for (int x = 0; x < RT_DIAG_EXTRA_LOADS; x++) RT_DIAG_LOAD(xv[x]);
 #endif
                     const float4 b0 = np[0], b1 = np[1], b2 = np[2];
                     const uint2 dsc = *reinterpret_cast<const uint2*>(np + 3);

@@ -677,13 +677,14 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     // Scenes of very many primitives: an 8-ary pyramid of union bounds over the primitives in index
     // order, for the TREE instantiation of the extend kernel.  Level 0 = the records of wbounds; an
     // entity of level L + 1 is the union of the existing slots of record e of level L.
-    // It pays from about 1500 primitives on (measured on instanced terrain: 3.4 vs 3.6 Grays/s at
-    // 1568 primitives, 1.1 vs 2.3 at 64800) -- if consecutive primitives are neighbours in space.  For
+    // It pays from about 500 primitives on (measured on instanced terrain, scan vs pyramid: 4.30 vs
+    // 4.17 Grays/s at 392 primitives, 4.23 vs 4.40 at 512, 3.47 vs 3.99 at 1568, 1.1 vs 2.5 at
+    // 64800) -- if consecutive primitives are neighbours in space.  For
     // a list in incoherent order every union bound spans the scene, the walk tests every record
     // lane by lane, and the wave-uniform chunk scan is the cheaper way to test everything (by a
     // third at 8192 shuffled instances).  Estimate of the box tests per ray: a record is tested when
     // the ray meets its entity, with probability area(entity) / area(scene) for a random ray.
-    uint32_t tree_min = 1536u;
+    uint32_t tree_min = 511u;
     if (const char* e = std::getenv("RTHIP_TREE_MIN_PRIMS")) tree_min = (uint32_t)std::strtoul(e, nullptr, 10); // tuning / test knob
     bool tree = s->n_prims > tree_min && s->n_prims > 8u && (uint64_t)s->n_prims <= (1ull << (3u * RT_TLAS_MAX_LEVELS));
     std::vector<float> tlas;

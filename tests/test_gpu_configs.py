@@ -309,13 +309,18 @@ def test_camera_cull_gives_the_masks_of_the_general_cull(ctx, atrium):
     assert np.array_equal(out["0"][2]["tri"], out["1"][2]["tri"])
 
 
-def test_ten_thousand_primitives_use_super_chunks(ctx):
+@pytest.mark.parametrize("walk", ["scan", "pyramid"])
+def test_ten_thousand_primitives_use_super_chunks(ctx, monkeypatch, walk):
     """10 368 instanced primitives = 81 chunks of 128, more than the 64 bits of a ray's chunk mask:
-    pairs of chunks form super-chunks.  Single rays bit for bit and a frame against the oracle."""
+    pairs of chunks form super-chunks.  Single rays bit for bit and a frame against the oracle, with
+    the chunk scan forced and with the bounds pyramid the library picks for such a list."""
     s = procedural.terrain_scene(tiles=72, n=8, env_size=(64, 32), instanced=True)
     a = s.arrays()
     assert a["prims"].shape[0] == 10368
+    if walk == "scan":
+        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000")
     ctx.upload_scene(a)
+    assert ctx.candidate_walk() == walk
     sc = oracle_scene(a)
     rng = np.random.default_rng(11)
     n = 300
@@ -346,19 +351,22 @@ def test_ten_thousand_primitives_use_super_chunks(ctx):
     assert np.array_equal(got["prim"][hit], ref["prim"][hit])
 
 
-@pytest.mark.parametrize("kind", ["atrium_cull_masks", "instanced_in_kernel_scan", "deep_stack"])
+@pytest.mark.parametrize("kind", ["atrium_cull_masks", "instanced_in_kernel_scan", "instanced_pyramid", "instanced_pyramid_deep_stack", "deep_stack"])
 def test_sun_shadow_rays_on_every_traversal_variant(ctx, atrium, kind):
     """The sun option's shadow rays (trace_shadow, shader.wgsl:528-575, 630-638: any hit, no alpha
     test, no distance bound) run on the any-hit form of the extend stage: with candidate masks from
     the cull stage (103 primitives, MASK materials that shadow rays must treat as opaque), with the
-    in-kernel candidate scan (162 instanced primitives) and with a traversal stack that continues
-    in global memory."""
+    in-kernel candidate scan (162 instanced primitives), with the walk of the bounds pyramid (800
+    instanced primitives) and with a traversal stack that continues in global memory."""
     if kind == "atrium_cull_masks":
         s, a = atrium
         res, depth = (320, 180), 23
     elif kind == "instanced_in_kernel_scan":
         s = procedural.terrain_scene(tiles=9, n=16, env_size=(64, 32), instanced=True)
         a, res, depth = s.arrays(), (192, 108), 23
+    elif kind.startswith("instanced_pyramid"):
+        s = procedural.terrain_scene(tiles=20, n=12, env_size=(64, 32), instanced=True)
+        a, res, depth = s.arrays(), (192, 108), (40 if kind.endswith("deep_stack") else 23)
     else:
         s = procedural.terrain_scene(tiles=6, env_size=(64, 32))
         a, res, depth = s.arrays(), (192, 108), 40
@@ -366,6 +374,7 @@ def test_sun_shadow_rays_on_every_traversal_variant(ctx, atrium, kind):
     p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
     u = s.frame_uniforms(res, frame=2, reject_hist=1)
     ctx.upload_scene(a)
+    assert ctx.candidate_walk() == {"atrium_cull_masks": "mask", "instanced_in_kernel_scan": "scan", "deep_stack": "mask"}.get(kind, "pyramid")
     ctx.set_frame_uniforms(u)
     ctx.reset_counters()
     ctx.render(2, 3, 1, p)

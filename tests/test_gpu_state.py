@@ -88,15 +88,20 @@ def test_render_of_zero_frames_settles_reject_hist():
         c.close()
 
 
-def test_sixty_four_super_chunks_and_rays_that_meet_none():
+@pytest.mark.parametrize("walk", ["scan", "pyramid"])
+def test_sixty_four_super_chunks_and_rays_that_meet_none(monkeypatch, walk):
     """8192 instanced primitives = 64 chunks of 128 = 64 super-chunks: every bit of a ray's chunk
-    mask names a real chunk, so a ray that meets none has an empty mask."""
+    mask names a real chunk, so a ray that meets none has an empty mask.  In the pyramid walk such a
+    ray meets no entity of the top record."""
     s = procedural.terrain_scene(tiles=64, n=8, env_size=(64, 32), instanced=True)
     a = s.arrays()
     assert a["prims"].shape[0] == 8192
+    if walk == "scan":
+        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000")
     c = device.Context(0)
     try:
         c.upload_scene(a)
+        assert c.candidate_walk() == walk
         sc = oracle_scene(a)
         rng = np.random.default_rng(5)
         n = 256
