@@ -236,3 +236,58 @@ def test_pyramid_only_for_long_lists_in_coherent_order(monkeypatch):
         assert c.candidate_walk() == "mask"
     finally:
         c.close()
+
+
+def test_pyramid_walk_keeps_the_order_that_blend_alpha_draws_depend_on(monkeypatch):
+    """BLEND materials draw from the path's random stream inside the traversal (shader.wgsl:464-487),
+    once per candidate hit, so the image depends on the order in which the primitives are visited.
+    290 MASK and BLEND cards over a floor, in rows: the pyramid walk must give the scan's image, taps
+    and alpha-test counts bit for bit, and the oracle's random-stream states."""
+    from raytracer_amd import layouts as L
+    from raytracer_amd import host
+    from oracle import orc as _orc
+    s = host.Scene()
+    leaves = s.add_texture(procedural.texture_leaves(64, 2))
+    floor = procedural.grid(16, 16, (40.0, 40.0), uv_scale=6.0)
+    s.add_primitive(floor[0], floor[1], normals=floor[2], uv0=floor[3], material=procedural.material(albedo=(0.7, 0.7, 0.7, 1)))
+    card = procedural.grid(3, 3, (1.6, 1.6), uv_scale=1.0)
+    where = lambda i, j: host.trs((-16.0 + 2.6 * i, -14.0 + 2.4 * j, 1.0 + 0.1 * ((i + j) % 3)), rot_y=np.pi / 2, rot_z=0.2 * j)
+    base = [s.add_primitive(card[0], card[1], normals=card[2], uv0=card[3], transform=where(0, k),
+                            material=procedural.material(albedo_tex=leaves, alpha_mode=mode, alpha_cutoff=0.4, roughness=0.8))
+            for k, mode in enumerate((L.ALPHA_MASK, L.ALPHA_BLEND))]
+    for i in range(12):
+        for j in range(12):
+            if i or j > 1:
+                s.add_instance(base[(i + j) & 1], where(i, j))
+    s.set_env(procedural.sky_env(64, 32))
+    s.add_camera(host.Camera.look((-24.0, -1.0, 2.2), yaw=0.0, pitch=np.radians(-4), fovy=np.radians(50), focus=10.0))
+    a = s.arrays()
+    assert a["prims"].shape[0] == 145
+    res = (320, 160)
+    p = device.default_params(max_bounces=4)
+    p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
+    u = s.frame_uniforms(res, frame=3, reject_hist=1)
+    out = {}
+    for walk in ("scan", "pyramid"):
+        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "8" if walk == "pyramid" else "4000000000")
+        c = device.Context(0)
+        try:
+            c.upload_scene(a)
+            assert c.candidate_walk() == walk
+            c.set_frame_uniforms(u)
+            c.reset_counters()
+            c.render(3, 2, 1, p)
+            out[walk] = dict(accum=c.read_accum(), counters=c.counters(), **c.read_taps())
+        finally:
+            c.close()
+    assert out["scan"]["counters"]["alpha_tests"] > 20000
+    assert np.array_equal(out["scan"]["accum"], out["pyramid"]["accum"])
+    for k in ("tri", "prim", "t", "seed"):
+        assert np.array_equal(out["scan"][k], out["pyramid"][k]), k
+    for k in ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests", "texel_fetches", "misses", "kills"):
+        assert out["scan"]["counters"][k] == out["pyramid"]["counters"][k], k
+    ref = _orc.render(oracle_scene(a), u, oracle_params(p), 3, 2, 1, taps=True, n_threads=16)
+    got = out["pyramid"]
+    assert float((got["tri"] == ref["tri"]).mean()) >= 0.999
+    assert float((got["seed"] == ref["seed"]).mean()) >= 0.997
+    assert abs(got["counters"]["alpha_tests"] - ref["counters"]["alpha_tests"]) <= 2e-3 * ref["counters"]["alpha_tests"]
