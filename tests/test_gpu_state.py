@@ -291,3 +291,49 @@ def test_pyramid_walk_keeps_the_order_that_blend_alpha_draws_depend_on(monkeypat
     assert float((got["tri"] == ref["tri"]).mean()) >= 0.999
     assert float((got["seed"] == ref["seed"]).mean()) >= 0.997
     assert abs(got["counters"]["alpha_tests"] - ref["counters"]["alpha_tests"]) <= 2e-3 * ref["counters"]["alpha_tests"]
+
+
+@pytest.mark.parametrize("walk", ["scan", "pyramid"])
+def test_coincident_instances_resolve_ties_by_primitive_order(monkeypatch, walk):
+    """Every tile placed twice with the same transform: both copies give the same t, and the
+    reference keeps the first one found (a later primitive wins only if strictly closer,
+    shader.wgsl:607-614).  The copies lie 200 places apart in the primitive list, in different
+    chunks and different records of the pyramid."""
+    from raytracer_amd import host
+    size = 40.0
+    t = procedural.terrain_mesh(8, size)
+    s = host.Scene()
+    mat = procedural.material(albedo=(0.8, 0.8, 0.8, 1))
+    pos = lambda k: host.trs(((k % 14 - 7 + 0.5) * size, (k // 14 - 7 + 0.5) * size, 0.0))
+    first = s.add_primitive(t[0], t[1], normals=t[2], uv0=t[3], material=mat, transform=pos(0))
+    for rep in range(2):
+        for k in range(200):
+            if rep or k:
+                s.add_instance(first, pos(k))
+    s.set_env(procedural.sky_env(64, 32))
+    s.add_camera(host.Camera.look((0.0, 0.0, 30.0), yaw=0.0, pitch=np.radians(-60), fovy=np.radians(60), focus=30.0))
+    a = s.arrays()
+    assert a["prims"].shape[0] == 400
+    monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "8" if walk == "pyramid" else "4000000000")
+    c = device.Context(0)
+    try:
+        c.upload_scene(a)
+        assert c.candidate_walk() == walk
+        rng = np.random.default_rng(3)
+        n = 400
+        o = np.column_stack([rng.uniform(-270, 270, n), rng.uniform(-270, 270, n), rng.uniform(5, 40, n)]).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[:, 2] = -np.abs(d[:, 2]) - 0.2
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        q = c.trace_rays(o, d)
+        sc = oracle_scene(a)
+        op = oracle_params(device.default_params())
+        hits = 0
+        for i in range(n):
+            tri, prim, tt, _ = orc.trace_ray(sc, o[i], d[i], op, 0)
+            assert q["tri"][i] == tri and (tri < 0 or (q["prim"][i] == prim and q["t"][i] == np.float32(tt))), i
+            hits += tri >= 0
+        assert hits > n // 2
+        assert np.all(q["prim"][q["tri"] >= 0] < 200)      # always the first copy
+    finally:
+        c.close()
