@@ -152,11 +152,14 @@ int rthip_frames_in_flight(rthip_ctx* ctx, uint32_t* n_frames);
  * tests every primitive for every ray, shader.wgsl:603): RTHIP_WALK_MASK = up to 128 primitives, one
  * bit mask per ray; RTHIP_WALK_SCAN = chunks of 128 primitives scanned wave by wave;
  * RTHIP_WALK_PYRAMID = per-ray walk of an 8-ary pyramid of bounds over the primitive list, chosen
- * for long lists whose neighbours are neighbours in space.  The result of a render does not depend
- * on it.  No counterpart upstream. */
+ * for long lists whose neighbours are neighbours in space; RTHIP_WALK_LIST = per-ray candidate lists,
+ * sorted by index, from a spatial tree over the primitives' bounds (rthip_render; ray queries of such
+ * a scene use the scan), chosen for long lists in an order that says nothing about space.  The
+ * result of a render does not depend on it.  No counterpart upstream. */
 #define RTHIP_WALK_MASK 0
 #define RTHIP_WALK_SCAN 1
 #define RTHIP_WALK_PYRAMID 2
+#define RTHIP_WALK_LIST 3
 int rthip_candidate_walk(rthip_ctx* ctx, uint32_t* kind);
 
 /* Use caller-owned DEVICE memory (n_pixels * 4 floats, 16-byte aligned) as the accumulator,

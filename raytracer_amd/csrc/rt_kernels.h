@@ -173,6 +173,8 @@ struct ExtArgs {
     // over the primitives in index order, and its directory
     const float4*   tlas;      // records of 192 bytes: the padded world bounds of eight consecutive entities of one level, [6 planes][8]
     const uint32_t* tlas_dir;  // [0] = top level T; [1 + L] = first record of level L; [1 + RT_TLAS_MAX_LEVELS + L] = entities at level L
+    // LIST instantiation only: per queue slot the 16-entry candidate list of k_cull_list
+    const uint32_t* lists;
 #ifdef RT_PROBE
     unsigned long long* probe; // diagnostic build: per wave (start, queue seen empty, end) in 100 MHz ticks and the most steps one of its rays took
 #endif
@@ -421,6 +423,94 @@ __global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ candidate lists
+//
+// Long primitive lists whose order says nothing about space (neither the chunk scan nor the bounds
+// pyramid can skip anything then): a binary tree over the primitives' padded world bounds, built
+// at upload by median splits, is walked per ray in a kernel of its own, and the primitives whose
+// bound the ray meets -- the candidates of trace(), shader.wgsl:603-615 -- are written out SORTED
+// by index, so that the extend stage still visits them in the reference's order.  A list has 16
+// entries: indices ascending, then RT_LIST_END; a ray with more candidates keeps its 15 smallest,
+// then RT_LIST_MORE, and the extend stage finds the rest by the chunk scan from the last listed
+// index on.  The walk has no distance bound and no order (every subtree the ray meets is visited).
+// Median splits make the tree complete but for its last level, so it is stored as a heap (node i
+// has the children 2i and 2i + 1, the root is 1) and walked without a stack: one bit per level
+// remembers that the right sibling of the path's node at that level is still to be visited, and
+// that sibling's index follows from the index of any of its nephews.  The list under construction
+// is an LDS column.
+#ifndef RT_LIST_LEN
+#define RT_LIST_LEN 16u
+#endif
+#define RT_LIST_END 0xFFFFFFFFu
+#define RT_LIST_MORE 0xFFFFFFFEu
+#define RT_LIST_LEAF 0x80000000u      // descriptor of a tree child that is a primitive; an inner child's is 0
+#define RT_LIST_MAX_DEPTH 24u         // 16.7 M primitives; the heap has 2^depth records
+
+struct CullListArgs {
+    const float4*   tree;   // heap of 64-byte records: the bounds of node i's two children (layout of the sibling pairs) + a descriptor each
+    PathQueue       in;
+    uint32_t*       lists;  // [slot][RT_LIST_LEN]
+    const uint32_t* count_in;
+};
+
+__global__ __launch_bounds__(256) void k_cull_list(CullListArgs a) {
+    __shared__ uint32_t lds_cand[RT_LIST_LEN * 256];
+    uint32_t* const cand = lds_cand + threadIdx.x;
+    const uint32_t n = *a.count_in;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t slot = base + threadIdx.x;
+        if (slot >= n) continue;
+        const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
+        if (__float_as_uint(s1.w) == RT_NO_PIXEL) continue;
+        f3 oi, idir;
+        world_test_ray(F3(s0.x, s0.y, s0.z), F3(s0.w, s1.x, s1.y), oi, idir);
+        uint32_t cnt = 0, node = 1, depth = 0, pending = 0;
+        bool dropped = false;
+        for (;;) {
+            const float4* np = rec16(a.tree, node * 4u);
+            const float4 b0 = np[0], b1 = np[1], b2 = np[2];
+            const uint2 dsc = *reinterpret_cast<const uint2*>(np + 3);
+            const float bl[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, br[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+            const bool hit[2] = {overlaps_world_box(oi, idir, bl), overlaps_world_box(oi, idir, br)};
+            const uint32_t child[2] = {dsc.x, dsc.y};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!hit[k] || !(child[k] & RT_LIST_LEAF)) continue;
+                // insert into the ascending list; the 17th candidate pushes the largest out
+                const uint32_t p = child[k] & ~RT_LIST_LEAF;
+                if (cnt == RT_LIST_LEN) {
+                    dropped = true;
+                    if (p > cand[(RT_LIST_LEN - 1u) * 256u]) continue;
+                    cnt = RT_LIST_LEN - 1u;
+                }
+                uint32_t i = cnt;
+                while (i > 0u && cand[(i - 1u) * 256u] > p) { cand[i * 256u] = cand[(i - 1u) * 256u]; i--; }
+                cand[i * 256u] = p;
+                cnt++;
+            }
+            const bool down_l = hit[0] && !(child[0] & RT_LIST_LEAF), down_r = hit[1] && !(child[1] & RT_LIST_LEAF);
+            if (down_l || down_r) {
+                depth++;
+                if (down_l && down_r) pending |= 1u << depth; // the right child, at the new depth
+                node = 2u * node + (down_l ? 0u : 1u);
+            } else {
+                if (pending == 0u) break;
+                const uint32_t level = 31u - (uint32_t)__builtin_clz(pending); // deepest sibling still to visit
+                pending &= ~(1u << level);
+                node = (node >> (depth - level)) | 1u; // the path's node at that level is a left child: its sibling
+                depth = level;
+            }
+        }
+        if (dropped && cnt == RT_LIST_LEN) cnt = RT_LIST_LEN - 1u;
+        uint32_t out[RT_LIST_LEN];
+#pragma unroll
+        for (uint32_t k = 0; k < RT_LIST_LEN; k++) out[k] = k < cnt ? cand[k * 256u] : ((k == cnt && dropped) ? RT_LIST_MORE : RT_LIST_END);
+        uint4* dst = reinterpret_cast<uint4*>(a.lists + (size_t)slot * RT_LIST_LEN);
+#pragma unroll
+        for (uint32_t k = 0; k < RT_LIST_LEN / 4u; k++) dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
+}
+
 // intersect_aabb on six separate bounds (the sibling-pair records), same arithmetic as hit_aabb_s
 __device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, float nz, float xx, float xy, float xz) {
     const float d0x = nx - o.x, d0y = ny - o.y, d0z = nz - o.z;
@@ -509,9 +599,16 @@ __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi 
 // of pending children per level.  One step tests the eight bounds of a record (twelve 16-byte
 // loads); steps are a fourth kind of round in the vote.
 #define RT_TLAS_MAX_LEVELS 8u   // 8^8 = 16.7 M primitives; a scene of more keeps the chunk scan
-template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false, bool TREE = false>
+//
+// LIST instantiation (with MULTI; long primitive lists in an order that says nothing about space):
+// the first candidates come, in index order, from the ray's list (k_cull_list), one dword load per
+// candidate; a list that ends in RT_LIST_MORE hands over to the chunk scan at the index after its
+// last entry.
+#define RT_LIST_SCANNING 0xFFu
+template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false, bool TREE = false, bool LIST = false>
 __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
     static_assert(!TREE || MULTI, "TREE is a variant of MULTI");
+    static_assert(!LIST || (MULTI && !TREE), "LIST is a variant of the scan");
     constexpr bool SCAN = MULTI && !TREE;
     constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
     __shared__ uint32_t lds_tlas_dir[1 + 2 * RT_TLAS_MAX_LEVELS];
@@ -561,6 +658,8 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
     uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes (MULTI); TREE: the next candidate primitive
     uint32_t tl = 0;                  // TREE: level << 28 | record of the pyramid the lane stands at
     unsigned long long tl_pending = 0; // TREE: byte L = children of the lane's record at level L still to visit
+    uint32_t li = 0;                  // LIST: next entry of the ray's candidate list, or RT_LIST_SCANNING once the scan has taken over
+    uint32_t scan_from = 0;           // LIST: first primitive the scan still has to look at
     unsigned long long cmask = ~0ull; // bit c: the ray meets the union bound of chunk c (c < 64)
     uint32_t pm = 0; // RT_PM_PRIM: current primitive; RT_PM_OVERFLOW: a push of this ray was dropped; top bits: alpha mode
     uint32_t cur_first = 0, cur_count = 0, sp = 0;
@@ -585,7 +684,24 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
     };
     // between primitives: next candidate of this chunk, else the next chunk, else the ray is done
     auto advance = [&]() {
-        if (TREE) {
+        if (LIST && li != RT_LIST_SCANNING) {
+            // cb holds the candidate itself while the list lasts
+            const uint32_t e = li < RT_LIST_LEN ? a.lists[(size_t)slot * RT_LIST_LEN + li] : RT_LIST_END;
+            if (e == RT_LIST_END) {
+                retire();
+            } else if (e == RT_LIST_MORE) {
+                scan_from = li != 0u ? cb + 1u : 0u; // the last listed candidate was the last one entered
+                li = RT_LIST_SCANNING;
+                cmask = ~0ull;
+                cb = scan_from & ~127u;
+                if (cb < sc.n_prims) st = ST_SCAN;
+                else retire();
+            } else {
+                cb = e;
+                li++;
+                st = ST_PRIM;
+            }
+        } else if (TREE) {
             // the next pending child, in ascending order: a primitive (level 0), a record to descend
             // into, or, when the top record is used up, the end of the ray
             const uint32_t top = lds_tlas_dir[0];
@@ -729,6 +845,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                         if (SCAN) cmask = ~0ull;
                         st = ST_SCAN;
                         if (TREE) { tl = lds_tlas_dir[0] << 28; tl_pending = 0ull; st = ST_TLAS; } // at the top record, untested
+                        if (LIST) { li = 0u; scan_from = 0u; }
                         fresh = true;
 #ifdef RT_PROBE
                         pr_max = max(pr_max, pr_steps);
@@ -750,7 +867,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                                 c_over += a.nan_dropped;
                             }
                             retire();
-                        } else if (!MULTI) {
+                        } else if (!MULTI || LIST) {
                             advance(); // first candidate, or done if the ray meets no primitive's bound
                         }
                     }
@@ -758,7 +875,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                 run_next += min(avail, n_done);
                 // scenes of more than one chunk: which (super-)chunks can the new rays touch at all
                 // (wave-uniform over their union bounds, scalar loads)
-                if (SCAN) {
+                if (SCAN && !LIST) {
                     const f3 r = rcp3(d);
                     const f3 idir = F3(fminf(fmaxf(r.x, -1e30f), 1e30f), fminf(fmaxf(r.y, -1e30f), 1e30f), fminf(fmaxf(r.z, -1e30f), 1e30f));
                     const f3 oi = F3(o.x * idir.x, o.y * idir.y, o.z * idir.z);
@@ -844,6 +961,13 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                 m[w] = have >= 32u ? mw : (mw & ((1u << have) - 1u));
             }
             if (mine) {
+                if (LIST) { // the scan took over behind the listed candidates: nothing below scan_from
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const uint32_t first = c0 + 32u * w;
+                        if (scan_from > first) m[w] = scan_from - first >= 32u ? 0u : (m[w] & ~((1u << (scan_from - first)) - 1u));
+                    }
+                }
                 mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];
                 advance(); // ST_PRIM if a bit is set, else on to the next chunk or done
             }
@@ -1020,7 +1144,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
 #endif
                 // next candidate in index order
                 uint32_t k = 0;
-                if (!TREE) {
+                if (!TREE && !(LIST && li != RT_LIST_SCANNING)) {
                     if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
                     else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
                     else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }

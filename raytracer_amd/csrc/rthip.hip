@@ -70,6 +70,10 @@ struct rthip_ctx {
     void*     d_tlas = nullptr;      // the bounds pyramid of a scene of many primitives, and its directory
     void*     d_tlas_dir = nullptr;
     bool      tree = false;          // the extend stage walks the pyramid instead of scanning chunks
+    void*     d_ptree = nullptr;     // spatial tree over the primitives' bounds, for the candidate lists
+    bool      lists = false;         // candidates come from per-ray lists (k_cull_list)
+    uint32_t* cand_lists = nullptr;  // [queue slot][RT_LIST_LEN]
+    uint64_t  cand_cap = 0;
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
     void*     d_env = nullptr;
@@ -164,7 +168,7 @@ template <typename T> void free_dev_t(T*& p) {
 }
 
 void free_scene(rthip_ctx* c) {
-    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_pbounds); free_dev(c->d_cbounds); free_dev(c->d_sbounds); free_dev(c->d_tlas); free_dev(c->d_tlas_dir); c->tree = false;
+    free_dev(c->d_nodes); free_dev(c->d_tris); free_dev(c->d_exts); free_dev(c->d_primx); free_dev(c->d_wbounds); free_dev(c->d_gbounds); free_dev(c->d_pairs); free_dev(c->d_pbounds); free_dev(c->d_cbounds); free_dev(c->d_sbounds); free_dev(c->d_tlas); free_dev(c->d_tlas_dir); c->tree = false; free_dev(c->d_ptree); c->lists = false;
     free_dev(c->d_prims); free_dev(c->d_texels); free_dev(c->d_env);
     c->have_scene = false;
 }
@@ -172,6 +176,8 @@ void free_scene(rthip_ctx* c) {
 // the per-frame work buffers: everything sized by the 8x8-tile slot count or the frame group
 void free_work_buffers(rthip_ctx* c) {
     free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
+    free_dev_t(c->cand_lists);
+    c->cand_cap = 0;
     c->shadow_cap = 0;
     c->spill_words = 0;
     c->frames_cap = 0;
@@ -231,10 +237,11 @@ uint32_t frames_in_flight_limit(const rthip_ctx* c) {
     uint64_t budget = 48ull << 30;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const uint64_t held = c->queue_mem ? c->queue_cap * 160ull : 0ull;
+        const uint64_t held = (c->queue_mem ? c->queue_cap * 160ull : 0ull) + c->cand_cap * 4ull * RT_LIST_LEN;
         budget = std::min<uint64_t>(budget, (free_b + held) / 2);
     }
-    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * 160ull > budget)) want--;
+    const uint64_t per_slot = 160ull + (c->lists ? 4ull * RT_LIST_LEN : 0ull); // + a candidate list where the scene uses them
+    while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * per_slot > budget)) want--;
     return want;
 }
 
@@ -339,8 +346,9 @@ template <typename K> int occupancy_blocks(K kernel, int block) {
 // k_extend has three compile-time switches; these pick the instantiation for run-time flags.
 // which instantiation walks a scene's primitives: one chunk with the masks of the cull stage, the
 // chunk scan, or the bounds pyramid
-enum ExtMode : int { EXT_SINGLE = 0, EXT_SCAN = 1, EXT_TREE = 2 };
+enum ExtMode : int { EXT_SINGLE = 0, EXT_SCAN = 1, EXT_TREE = 2, EXT_LIST = 3 };
 template <bool COUNT, bool DEEP> int extend_occupancy_t(ExtMode m) {
+    if (m == EXT_LIST) return occupancy_blocks(k_extend<COUNT, DEEP, true, false, false, true>, 256);
     if (m == EXT_TREE) return occupancy_blocks(k_extend<COUNT, DEEP, true, false, true>, 256);
     return m == EXT_SCAN ? occupancy_blocks(k_extend<COUNT, DEEP, true>, 256) : occupancy_blocks(k_extend<COUNT, DEEP, false>, 256);
 }
@@ -349,12 +357,14 @@ int extend_occupancy(bool count, bool deep, ExtMode m) {
     return deep ? extend_occupancy_t<false, true>(m) : extend_occupancy_t<false, false>(m);
 }
 template <bool COUNT, bool DEEP> void extend_launch_t(ExtMode m, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
-    if (m == EXT_TREE) hipLaunchKernelGGL((k_extend<COUNT, DEEP, true, false, true>), dim3(grid), dim3(256), 0, st, ea);
+    if (m == EXT_LIST) hipLaunchKernelGGL((k_extend<COUNT, DEEP, true, false, false, true>), dim3(grid), dim3(256), 0, st, ea);
+    else if (m == EXT_TREE) hipLaunchKernelGGL((k_extend<COUNT, DEEP, true, false, true>), dim3(grid), dim3(256), 0, st, ea);
     else if (m == EXT_SCAN) hipLaunchKernelGGL((k_extend<COUNT, DEEP, true>), dim3(grid), dim3(256), 0, st, ea);
     else hipLaunchKernelGGL((k_extend<COUNT, DEEP, false>), dim3(grid), dim3(256), 0, st, ea);
 }
 template <bool DEEP> void shadow_extend_launch_t(ExtMode m, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
-    if (m == EXT_TREE) hipLaunchKernelGGL((k_extend<false, DEEP, true, true, true>), dim3(grid), dim3(256), 0, st, ea);
+    if (m == EXT_LIST) hipLaunchKernelGGL((k_extend<false, DEEP, true, true, false, true>), dim3(grid), dim3(256), 0, st, ea);
+    else if (m == EXT_TREE) hipLaunchKernelGGL((k_extend<false, DEEP, true, true, true>), dim3(grid), dim3(256), 0, st, ea);
     else if (m == EXT_SCAN) hipLaunchKernelGGL((k_extend<false, DEEP, true, true>), dim3(grid), dim3(256), 0, st, ea);
     else hipLaunchKernelGGL((k_extend<false, DEEP, false, true>), dim3(grid), dim3(256), 0, st, ea);
 }
@@ -731,6 +741,70 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         }
         if (!std::getenv("RTHIP_TREE_MIN_PRIMS") && !(tests < 0.5 * (double)s->n_prims)) tree = false;
     }
+    // A long list that is not coherent gets per-ray candidate lists from a spatial tree over the
+    // primitives' bounds instead (k_cull_list): median splits of the centroids along the longest
+    // axis, one primitive per leaf, stored as a heap (node i: children 2i and 2i + 1) of 2^depth
+    // records.  Primitives without a finite bound cannot be placed in it; such a scene keeps the scan.
+    bool lists = !tree && s->n_prims > tree_min && s->n_prims > 128u && !std::getenv("RTHIP_TREE_MIN_PRIMS");
+    if (const char* e = std::getenv("RTHIP_CANDIDATE_WALK")) { // test / tuning knob: scan, pyramid or list for any scene of more than 128 primitives
+        const std::string want(e);
+        if (s->n_prims > 128u && (want == "scan" || want == "pyramid" || want == "list")) {
+            lists = want == "list";
+            if (want == "pyramid" && tlas.empty()) return fail(c, RTHIP_ERR_INVALID, "upload_scene: RTHIP_CANDIDATE_WALK=pyramid needs RTHIP_TREE_MIN_PRIMS below the primitive count");
+            tree = want == "pyramid";
+        }
+    }
+    uint32_t ptree_depth = 0;
+    while ((1ull << ptree_depth) < s->n_prims) ptree_depth++;
+    if (ptree_depth > RT_LIST_MAX_DEPTH) lists = false;
+    for (uint32_t p = 0; p < s->n_prims && lists; p++)
+        for (int k = 0; k < 6; k++) lists = lists && std::isfinite(pbounds[(size_t)p * 8 + k]);
+    std::vector<uint32_t> ptree;
+    if (lists) {
+        const uint32_t np = s->n_prims;
+        std::vector<uint32_t> order(np);
+        for (uint32_t p = 0; p < np; p++) order[p] = p;
+        auto centre = [&](uint32_t p, int ax) { return 0.5f * pbounds[(size_t)p * 8 + ax] + 0.5f * pbounds[(size_t)p * 8 + 3 + ax]; };
+        struct Range { uint32_t begin, end, node; };
+        ptree.assign((size_t)16 << ptree_depth, 0u);
+        std::vector<Range> todo{{0u, np, 1u}};
+        auto bound_of = [&](uint32_t b, uint32_t e, float* out) {
+            const float inf = std::numeric_limits<float>::infinity();
+            for (int k = 0; k < 3; k++) { out[k] = inf; out[3 + k] = -inf; }
+            for (uint32_t i = b; i < e; i++)
+                for (int k = 0; k < 3; k++) {
+                    out[k] = std::min(out[k], pbounds[(size_t)order[i] * 8 + k]);
+                    out[3 + k] = std::max(out[3 + k], pbounds[(size_t)order[i] * 8 + 3 + k]);
+                }
+        };
+        while (!todo.empty()) {
+            const Range r = todo.back();
+            todo.pop_back();
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; }
+            for (uint32_t i = r.begin; i < r.end; i++)
+                for (int k = 0; k < 3; k++) { const float v = centre(order[i], k); lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); }
+            int ax = 0;
+            if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1;
+            if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+            const uint32_t mid = r.begin + (r.end - r.begin + 1u) / 2; // the larger half goes left: no level is started before the one above is full
+            std::nth_element(order.begin() + r.begin, order.begin() + mid, order.begin() + r.end,
+                             [&](uint32_t x, uint32_t y) { const float cx = centre(x, ax), cy = centre(y, ax); return cx < cy || (cx == cy && x < y); });
+            uint32_t* rec = &ptree[(size_t)r.node * 16];
+            const uint32_t half[2][2] = {{r.begin, mid}, {mid, r.end}};
+            for (uint32_t ch = 0; ch < 2; ch++) {
+                float b[6];
+                bound_of(half[ch][0], half[ch][1], b);
+                std::memcpy(rec + 6 * ch, b, 24);
+                if (half[ch][1] - half[ch][0] == 1u) {
+                    rec[12 + ch] = RT_LIST_LEAF | order[half[ch][0]];
+                } else {
+                    rec[12 + ch] = 0u;
+                    todo.push_back({half[ch][0], half[ch][1], 2u * r.node + ch});
+                }
+            }
+        }
+    }
 
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -750,6 +824,10 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     HIP_TRY(c, upload(c->d_pbounds, pbounds.data(), sizeof(float) * pbounds.size()));
     HIP_TRY(c, upload(c->d_cbounds, cbounds.data(), sizeof(float) * cbounds.size()));
     HIP_TRY(c, upload(c->d_sbounds, sbounds.data(), sizeof(float) * sbounds.size()));
+    if (lists) {
+        HIP_TRY(c, upload(c->d_ptree, ptree.data(), sizeof(uint32_t) * ptree.size()));
+        c->lists = true;
+    }
     if (tree) {
         HIP_TRY(c, upload(c->d_tlas, tlas.data(), sizeof(float) * tlas.size()));
         HIP_TRY(c, upload(c->d_tlas_dir, tlas_dir.data(), sizeof(uint32_t) * tlas_dir.size()));
@@ -909,7 +987,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
 
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const bool multi = c->sc.n_chunks > 1u;
-    const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : EXT_SCAN);
+    const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : (c->lists ? EXT_LIST : EXT_SCAN));
     const bool deep = P.stack_depth > rt_lds_levels(multi);
     // with a handful of primitives the candidate test saves less than it costs
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
@@ -938,6 +1016,13 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             c->shadow_cap = 0;
             HIP_TRY(c, hipMalloc((void**)&c->shadow_mem, sizeof(float4) * 4 * c->queue_cap));
             c->shadow_cap = c->queue_cap;
+        }
+        if (ext_mode == EXT_LIST && c->cand_cap < c->queue_cap) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            free_dev_t(c->cand_lists);
+            c->cand_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->cand_lists, sizeof(uint32_t) * RT_LIST_LEN * c->queue_cap));
+            c->cand_cap = c->queue_cap;
         }
         if (deep) { // stack levels beyond the LDS part: one dword column per thread of the extend grid
             const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi)) * ext_grid * 256;
@@ -968,8 +1053,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         for (uint32_t b = 0; b < P.max_bounces; b++) {
             ExtArgs ea{};
             ea.sc = c->sc;
-    ea.tlas = static_cast<const float4*>(c->d_tlas);
-    ea.tlas_dir = static_cast<const uint32_t*>(c->d_tlas_dir);
+            ea.tlas = static_cast<const float4*>(c->d_tlas);
+            ea.tlas_dir = static_cast<const uint32_t*>(c->d_tlas_dir);
+            ea.lists = c->cand_lists;
             ea.in = q[b & 1];
             ea.hits = c->hits;
             ea.spill = c->spill;
@@ -998,6 +1084,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 // camera rays: a wave's slots are one pixel tile, whose rays meet few primitives
                 if (b == 0 && cull_camera) hipLaunchKernelGGL(k_cull_camera, dim3(shade_grid), dim3(256), 0, c->stream, ca);
                 else hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
+            }
+            if (ext_mode == EXT_LIST) {
+                CullListArgs la{static_cast<const float4*>(c->d_ptree), q[b & 1], c->cand_lists, c->ctrl + b};
+                StageTimer t(c, timing, RTHIP_STAGE_CULL);
+                hipLaunchKernelGGL(k_cull_list, dim3(shade_grid), dim3(256), 0, c->stream, la);
             }
 #ifdef RT_PROBE
             // diagnostic build only (tools/tail_probe.py): per-wave timestamps of this launch appended to $RTHIP_PROBE_FILE
@@ -1067,6 +1158,10 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                     ca.count_in = xa.count_in;
                     hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
                 }
+                if (ext_mode == EXT_LIST) {
+                    CullListArgs la{static_cast<const float4*>(c->d_ptree), sa.shadow, c->cand_lists, xa.count_in};
+                    hipLaunchKernelGGL(k_cull_list, dim3(shade_grid), dim3(256), 0, c->stream, la);
+                }
                 shadow_extend_launch(deep, ext_mode, ext_grid, c->stream, xa);
                 ShadowArgs wa{};
                 wa.in = sa.shadow;
@@ -1105,7 +1200,7 @@ int rthip_candidate_walk(rthip_ctx* c, uint32_t* kind) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!kind) return fail(c, RTHIP_ERR_INVALID, "candidate_walk: null output");
     if (!c->have_scene) return fail(c, RTHIP_ERR_STATE, "candidate_walk: no scene uploaded");
-    *kind = c->sc.n_chunks <= 1u ? RTHIP_WALK_MASK : (c->tree ? RTHIP_WALK_PYRAMID : RTHIP_WALK_SCAN);
+    *kind = c->sc.n_chunks <= 1u ? RTHIP_WALK_MASK : (c->tree ? RTHIP_WALK_PYRAMID : (c->lists ? RTHIP_WALK_LIST : RTHIP_WALK_SCAN));
     return RTHIP_OK;
 }
 

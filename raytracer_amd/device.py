@@ -230,10 +230,10 @@ class Context:
         return int(n.value)
 
     def candidate_walk(self):
-        """How the uploaded scene's primitives are enumerated per ray: "mask", "scan" or "pyramid"."""
+        """How the uploaded scene's primitives are enumerated per ray: "mask", "scan", "pyramid" or "list"."""
         k = C.c_uint32()
         self._check(lib().rthip_candidate_walk(self._h, C.byref(k)))
-        return ("mask", "scan", "pyramid")[k.value]
+        return ("mask", "scan", "pyramid", "list")[k.value]
 
     def copy_bandwidth(self, nbytes=1 << 30, repeats=8):
         """Device-to-device stream-copy ceiling in GB/s (read + write traffic)."""

@@ -92,7 +92,7 @@ extern "C" {
     pub fn rthip_trace_rays_noalloc(ctx: *mut rthip_ctx, d_rays6: *const f32, d_seeds: *mut u32, n: u64, params: *const rthip_render_params,
                                     d_t: *mut f32, d_tri_idx: *mut i32, d_prim_idx: *mut i32, d_overflow: *mut u8) -> c_int;
     pub fn rthip_frames_in_flight(ctx: *mut rthip_ctx, n_frames: *mut u32) -> c_int;
-    /// 0 = one mask per ray, 1 = chunk scan, 2 = bounds pyramid.
+    /// 0 = one mask per ray, 1 = chunk scan, 2 = bounds pyramid, 3 = per-ray candidate lists.
     pub fn rthip_candidate_walk(ctx: *mut rthip_ctx, kind: *mut u32) -> c_int;
     pub fn rthip_copy_bandwidth(ctx: *mut rthip_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;
     pub fn rthip_bind_accum(ctx: *mut rthip_ctx, device_ptr: *mut c_void, n_pixels: u64) -> c_int;

@@ -309,7 +309,7 @@ def test_camera_cull_gives_the_masks_of_the_general_cull(ctx, atrium):
     assert np.array_equal(out["0"][2]["tri"], out["1"][2]["tri"])
 
 
-@pytest.mark.parametrize("walk", ["scan", "pyramid"])
+@pytest.mark.parametrize("walk", ["scan", "pyramid", "list"])
 def test_ten_thousand_primitives_use_super_chunks(ctx, monkeypatch, walk):
     """10 368 instanced primitives = 81 chunks of 128, more than the 64 bits of a ray's chunk mask:
     pairs of chunks form super-chunks.  Single rays bit for bit and a frame against the oracle, with
@@ -319,6 +319,8 @@ def test_ten_thousand_primitives_use_super_chunks(ctx, monkeypatch, walk):
     assert a["prims"].shape[0] == 10368
     if walk == "scan":
         monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000")
+    elif walk == "list":   # per-ray candidate lists in the frame below; the single rays of such a scene take the scan
+        monkeypatch.setenv("RTHIP_CANDIDATE_WALK", "list")
     ctx.upload_scene(a)
     assert ctx.candidate_walk() == walk
     sc = oracle_scene(a)
@@ -351,21 +353,23 @@ def test_ten_thousand_primitives_use_super_chunks(ctx, monkeypatch, walk):
     assert np.array_equal(got["prim"][hit], ref["prim"][hit])
 
 
-@pytest.mark.parametrize("kind", ["atrium_cull_masks", "instanced_in_kernel_scan", "instanced_pyramid", "instanced_pyramid_deep_stack", "deep_stack"])
+@pytest.mark.parametrize("kind", ["atrium_cull_masks", "instanced_in_kernel_scan", "instanced_pyramid", "instanced_pyramid_deep_stack", "instanced_lists", "instanced_lists_deep_stack", "deep_stack"])
 def test_sun_shadow_rays_on_every_traversal_variant(ctx, atrium, kind):
     """The sun option's shadow rays (trace_shadow, shader.wgsl:528-575, 630-638: any hit, no alpha
     test, no distance bound) run on the any-hit form of the extend stage: with candidate masks from
     the cull stage (103 primitives, MASK materials that shadow rays must treat as opaque), with the
-    in-kernel candidate scan (162 instanced primitives), with the walk of the bounds pyramid (800
-    instanced primitives) and with a traversal stack that continues in global memory."""
+    in-kernel candidate scan (162 instanced primitives), with the walk of the bounds pyramid and with
+    per-ray candidate lists (800 instanced primitives in rows / shuffled) and with a traversal stack
+    that continues in global memory."""
     if kind == "atrium_cull_masks":
         s, a = atrium
         res, depth = (320, 180), 23
     elif kind == "instanced_in_kernel_scan":
         s = procedural.terrain_scene(tiles=9, n=16, env_size=(64, 32), instanced=True)
         a, res, depth = s.arrays(), (192, 108), 23
-    elif kind.startswith("instanced_pyramid"):
-        s = procedural.terrain_scene(tiles=20, n=12, env_size=(64, 32), instanced=True)
+    elif kind.startswith("instanced_pyramid") or kind.startswith("instanced_lists"):
+        # 800 primitives, in rows (the pyramid) or shuffled (per-ray lists from the spatial tree)
+        s = procedural.terrain_scene(tiles=20, n=12, env_size=(64, 32), instanced=True, shuffled=kind.startswith("instanced_lists"))
         a, res, depth = s.arrays(), (192, 108), (40 if kind.endswith("deep_stack") else 23)
     else:
         s = procedural.terrain_scene(tiles=6, env_size=(64, 32))
@@ -374,7 +378,7 @@ def test_sun_shadow_rays_on_every_traversal_variant(ctx, atrium, kind):
     p.flags |= device.FLAG_TAPS | device.FLAG_COUNTERS
     u = s.frame_uniforms(res, frame=2, reject_hist=1)
     ctx.upload_scene(a)
-    assert ctx.candidate_walk() == {"atrium_cull_masks": "mask", "instanced_in_kernel_scan": "scan", "deep_stack": "mask"}.get(kind, "pyramid")
+    assert ctx.candidate_walk() == {"atrium_cull_masks": "mask", "instanced_in_kernel_scan": "scan", "deep_stack": "mask"}.get(kind, "list" if "lists" in kind else "pyramid")
     ctx.set_frame_uniforms(u)
     ctx.reset_counters()
     ctx.render(2, 3, 1, p)

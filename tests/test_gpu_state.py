@@ -10,6 +10,18 @@ from util import oracle_params, oracle_scene
 pytestmark = pytest.mark.gpu
 
 
+def force_walk(monkeypatch, walk):
+    """Environment that makes the next upload_scene of a scene of more than 128 primitives use `walk`."""
+    monkeypatch.delenv("RTHIP_TREE_MIN_PRIMS", raising=False)
+    monkeypatch.delenv("RTHIP_CANDIDATE_WALK", raising=False)
+    if walk == "pyramid":
+        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "8")
+    elif walk == "scan":
+        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000")
+    elif walk == "list":
+        monkeypatch.setenv("RTHIP_CANDIDATE_WALK", "list")
+
+
 def fresh(scene, arrays, res, first, n, params=None):
     c = device.Context(0)
     try:
@@ -147,7 +159,9 @@ def test_frames_in_flight_reports_the_group_size_in_use(monkeypatch):
 @pytest.mark.parametrize("tiles,n_mesh", [(9, 8), (16, 8), (33, 4)])
 def test_bounds_pyramid_walk_equals_chunk_scan(monkeypatch, tiles, n_mesh):
     """Scenes of many primitives take their candidates from a walk of an 8-ary pyramid of union
-    bounds instead of the chunk scan.  Forced on for small scenes (162, 512 and 2178 primitives: three and
+    bounds, or from per-ray lists made by a walk of a spatial tree, instead of the chunk scan.  The
+    ground camera looks along the rows of tiles, so many rays have more candidates than a list
+    holds and finish with the scan.  Forced on for small scenes (162, 512 and 2178 primitives: three and
     four levels, full and ragged last records), it must give the same image, taps and traversal counters as
     the scan, and ray queries equal to the oracle's."""
     s = procedural.terrain_scene(tiles=tiles, n=n_mesh, env_size=(64, 32), instanced=True)
@@ -157,12 +171,12 @@ def test_bounds_pyramid_walk_equals_chunk_scan(monkeypatch, tiles, n_mesh):
     p = device.default_params()
     p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
 
-    def run(tree):
-        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "8" if tree else "4000000000")
+    def run(walk):
+        force_walk(monkeypatch, walk)
         c = device.Context(0)
         try:
             c.upload_scene(a)
-            assert c.candidate_walk() == ("pyramid" if tree else "scan")
+            assert c.candidate_walk() == walk
             c.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
             c.reset_counters()
             c.render(1, 3, 1, p)
@@ -180,12 +194,13 @@ def test_bounds_pyramid_walk_equals_chunk_scan(monkeypatch, tiles, n_mesh):
         finally:
             c.close()
 
-    scan, tree = run(False), run(True)
-    assert np.array_equal(scan["accum"], tree["accum"])
-    for k in ("tri", "prim", "t", "seed"):
-        assert np.array_equal(scan[k], tree[k]), k
-    for k in ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "shade_calls", "misses", "kills", "stack_overflows", "paths"):
-        assert scan["counters"][k] == tree["counters"][k], k
+    scan, tree, lists = run("scan"), run("pyramid"), run("list")
+    for other in (tree, lists):
+        assert np.array_equal(scan["accum"], other["accum"])
+        for k in ("tri", "prim", "t", "seed"):
+            assert np.array_equal(scan[k], other[k]), k
+        for k in ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "shade_calls", "misses", "kills", "stack_overflows", "paths"):
+            assert scan["counters"][k] == other["counters"][k], k
     sc = oracle_scene(a)
     op = oracle_params(device.default_params())
     o, d = tree["rays"]
@@ -199,11 +214,11 @@ def test_bounds_pyramid_walk_equals_chunk_scan(monkeypatch, tiles, n_mesh):
     assert hits > len(o) // 8
 
 
-def test_pyramid_only_for_long_lists_in_coherent_order(monkeypatch):
+def test_pyramid_for_coherent_and_lists_for_incoherent_long_primitive_lists(monkeypatch):
     """Row-major tiles: consecutive primitives are neighbours, bounds over index ranges are tight.
-    The same instances in shuffled order: every range spans the scene and the chunk scan is kept.
-    Either way the image is the same as the other walk's (the order of the list differs between the
-    two scenes, so each is compared with itself)."""
+    The same instances in shuffled order: every range spans the scene, and the candidates come from
+    per-ray lists made with a spatial tree instead.  Either way the image is the chunk scan's (the
+    order of the list differs between the two scenes, so each is compared with itself)."""
     monkeypatch.delenv("RTHIP_TREE_MIN_PRIMS", raising=False)
     kinds = {}
     for shuffled in (False, True):
@@ -217,16 +232,16 @@ def test_pyramid_only_for_long_lists_in_coherent_order(monkeypatch):
             c.set_frame_uniforms(s.frame_uniforms((96, 64), frame=1, reject_hist=1))
             c.render(1, 2, 1, device.default_params())
             own = c.read_accum()
-            monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000" if kinds[shuffled] == "pyramid" else "8")
+            monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000")
             c.upload_scene(a)
-            assert c.candidate_walk() != kinds[shuffled]
+            assert c.candidate_walk() == "scan"
             c.set_frame_uniforms(s.frame_uniforms((96, 64), frame=1, reject_hist=1))
             c.render(1, 2, 1, device.default_params())
             assert np.array_equal(own, c.read_accum())
             monkeypatch.delenv("RTHIP_TREE_MIN_PRIMS")
         finally:
             c.close()
-    assert kinds == {False: "pyramid", True: "scan"}
+    assert kinds == {False: "pyramid", True: "list"}
     small = procedural.box_scene(env_size=(64, 32))
     c = device.Context(0)
     try:
@@ -268,8 +283,8 @@ def test_pyramid_walk_keeps_the_order_that_blend_alpha_draws_depend_on(monkeypat
     p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
     u = s.frame_uniforms(res, frame=3, reject_hist=1)
     out = {}
-    for walk in ("scan", "pyramid"):
-        monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "8" if walk == "pyramid" else "4000000000")
+    for walk in ("scan", "pyramid", "list"):
+        force_walk(monkeypatch, walk)
         c = device.Context(0)
         try:
             c.upload_scene(a)
@@ -281,11 +296,12 @@ def test_pyramid_walk_keeps_the_order_that_blend_alpha_draws_depend_on(monkeypat
         finally:
             c.close()
     assert out["scan"]["counters"]["alpha_tests"] > 20000
-    assert np.array_equal(out["scan"]["accum"], out["pyramid"]["accum"])
-    for k in ("tri", "prim", "t", "seed"):
-        assert np.array_equal(out["scan"][k], out["pyramid"][k]), k
-    for k in ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests", "texel_fetches", "misses", "kills"):
-        assert out["scan"]["counters"][k] == out["pyramid"]["counters"][k], k
+    for walk in ("pyramid", "list"):
+        assert np.array_equal(out["scan"]["accum"], out[walk]["accum"]), walk
+        for k in ("tri", "prim", "t", "seed"):
+            assert np.array_equal(out["scan"][k], out[walk][k]), (walk, k)
+        for k in ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests", "texel_fetches", "misses", "kills"):
+            assert out["scan"]["counters"][k] == out[walk]["counters"][k], (walk, k)
     ref = _orc.render(oracle_scene(a), u, oracle_params(p), 3, 2, 1, taps=True, n_threads=16)
     got = out["pyramid"]
     assert float((got["tri"] == ref["tri"]).mean()) >= 0.999

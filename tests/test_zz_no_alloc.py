@@ -47,7 +47,7 @@ def compare(ctx, torch, arrays, n, seed, params):
     return ref
 
 
-@pytest.mark.parametrize("scene_name", ["materials", "terrain_deep", "instanced", "instanced_pyramid"])
+@pytest.mark.parametrize("scene_name", ["materials", "terrain_deep", "instanced", "instanced_pyramid", "instanced_lists"])
 def test_noalloc_equals_trace_rays_twice_in_a_row(scene_name):
     import torch
     if scene_name == "materials":
@@ -56,13 +56,15 @@ def test_noalloc_equals_trace_rays_twice_in_a_row(scene_name):
         s, params, sizes = procedural.terrain_scene(tiles=6, env_size=(64, 32)), device.default_params(stack_depth=40), (50000, 777)
     elif scene_name == "instanced":     # more than 128 primitives: the in-kernel candidate scan
         s, params, sizes = procedural.terrain_scene(tiles=10, n=12, env_size=(64, 32), instanced=True), device.default_params(), (device.NOALLOC_MAX_RAYS, 64)
-    else:                               # a long primitive list: the walk of the bounds pyramid, with a deep stack as well
-        s, params, sizes = procedural.terrain_scene(tiles=18, n=8, env_size=(64, 32), instanced=True), device.default_params(stack_depth=40), (90000, 1000)
+    else:                               # a long primitive list: the walk of the bounds pyramid, with a deep stack as well;
+                                        # in shuffled order a render would use per-ray lists, ray queries take the scan
+        s, params, sizes = (procedural.terrain_scene(tiles=18, n=8, env_size=(64, 32), instanced=True, shuffled=scene_name.endswith("lists")),
+                            device.default_params(stack_depth=40), (90000, 1000))
     a = s.arrays()
     ctx = device.Context(0)
     try:
         ctx.upload_scene(a)
-        assert ctx.candidate_walk() == {"instanced": "scan", "instanced_pyramid": "pyramid"}.get(scene_name, "mask")
+        assert ctx.candidate_walk() == {"instanced": "scan", "instanced_pyramid": "pyramid", "instanced_lists": "list"}.get(scene_name, "mask")
         first = compare(ctx, torch, a, sizes[0], 1, params)
         second = compare(ctx, torch, a, sizes[1], 2, params)   # fewer rays: the work array still holds the first call's
         assert (first["tri"] >= 0).any() and (second["tri"] >= 0).any()
