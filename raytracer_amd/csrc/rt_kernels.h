@@ -173,8 +173,9 @@ struct ExtArgs {
     // over the primitives in index order, and its directory
     const float4*   tlas;      // records of 192 bytes: the padded world bounds of eight consecutive entities of one level, [6 planes][8]
     const uint32_t* tlas_dir;  // [0] = top level T; [1 + L] = first record of level L; [1 + RT_TLAS_MAX_LEVELS + L] = entities at level L
-    // LIST instantiation only: per queue slot the 16-entry candidate list of k_cull_list
+    // LIST instantiation only: per queue slot the candidate list of k_cull_list, and its length in entries
     const uint32_t* lists;
+    uint32_t        list_len;
 #ifdef RT_PROBE
     unsigned long long* probe; // diagnostic build: per wave (start, queue seen empty, end) in 100 MHz ticks and the most steps one of its rays took
 #endif
@@ -430,17 +431,16 @@ __global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
 // at upload by median splits, is walked per ray in a kernel of its own, and the primitives whose
 // bound the ray meets -- the candidates of trace(), shader.wgsl:603-615 -- are written out SORTED
 // by index, so that the extend stage still visits them in the reference's order.  A list has 16
-// entries: indices ascending, then RT_LIST_END; a ray with more candidates keeps its 15 smallest,
-// then RT_LIST_MORE, and the extend stage finds the rest by the chunk scan from the last listed
+// (or 32) entries: indices ascending, then RT_LIST_END; a ray with more candidates keeps all but
+// one entry's worth of its smallest, then RT_LIST_MORE, and the extend stage finds the rest by the chunk scan from the last listed
 // index on.  The walk has no distance bound and no order (every subtree the ray meets is visited).
 // Median splits make the tree complete but for its last level, so it is stored as a heap (node i
 // has the children 2i and 2i + 1, the root is 1) and walked without a stack: one bit per level
 // remembers that the right sibling of the path's node at that level is still to be visited, and
 // that sibling's index follows from the index of any of its nephews.  The list under construction
 // is an LDS column.
-#ifndef RT_LIST_LEN
-#define RT_LIST_LEN 16u
-#endif
+#define RT_LIST_LEN 16u               // entries of a list; RT_LIST_LEN_LONG for the longest primitive lists (rthip_upload_scene picks)
+#define RT_LIST_LEN_LONG 32u
 #define RT_LIST_END 0xFFFFFFFFu
 #define RT_LIST_MORE 0xFFFFFFFEu
 #define RT_LIST_LEAF 0x80000000u      // descriptor of a tree child that is a primitive; an inner child's is 0
@@ -449,12 +449,13 @@ __global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
 struct CullListArgs {
     const float4*   tree;   // heap of 64-byte records: the bounds of node i's two children (layout of the sibling pairs) + a descriptor each
     PathQueue       in;
-    uint32_t*       lists;  // [slot][RT_LIST_LEN]
+    uint32_t*       lists;  // [slot][LEN]
     const uint32_t* count_in;
 };
 
+template <uint32_t LEN>
 __global__ __launch_bounds__(256) void k_cull_list(CullListArgs a) {
-    __shared__ uint32_t lds_cand[RT_LIST_LEN * 256];
+    __shared__ uint32_t lds_cand[LEN * 256];
     uint32_t* const cand = lds_cand + threadIdx.x;
     const uint32_t n = *a.count_in;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
@@ -478,10 +479,10 @@ __global__ __launch_bounds__(256) void k_cull_list(CullListArgs a) {
                 if (!hit[k] || !(child[k] & RT_LIST_LEAF)) continue;
                 // insert into the ascending list; the 17th candidate pushes the largest out
                 const uint32_t p = child[k] & ~RT_LIST_LEAF;
-                if (cnt == RT_LIST_LEN) {
+                if (cnt == LEN) {
                     dropped = true;
-                    if (p > cand[(RT_LIST_LEN - 1u) * 256u]) continue;
-                    cnt = RT_LIST_LEN - 1u;
+                    if (p > cand[(LEN - 1u) * 256u]) continue;
+                    cnt = LEN - 1u;
                 }
                 uint32_t i = cnt;
                 while (i > 0u && cand[(i - 1u) * 256u] > p) { cand[i * 256u] = cand[(i - 1u) * 256u]; i--; }
@@ -501,13 +502,13 @@ __global__ __launch_bounds__(256) void k_cull_list(CullListArgs a) {
                 depth = level;
             }
         }
-        if (dropped && cnt == RT_LIST_LEN) cnt = RT_LIST_LEN - 1u;
-        uint32_t out[RT_LIST_LEN];
+        if (dropped && cnt == LEN) cnt = LEN - 1u;
+        uint32_t out[LEN];
 #pragma unroll
-        for (uint32_t k = 0; k < RT_LIST_LEN; k++) out[k] = k < cnt ? cand[k * 256u] : ((k == cnt && dropped) ? RT_LIST_MORE : RT_LIST_END);
-        uint4* dst = reinterpret_cast<uint4*>(a.lists + (size_t)slot * RT_LIST_LEN);
+        for (uint32_t k = 0; k < LEN; k++) out[k] = k < cnt ? cand[k * 256u] : ((k == cnt && dropped) ? RT_LIST_MORE : RT_LIST_END);
+        uint4* dst = reinterpret_cast<uint4*>(a.lists + (size_t)slot * LEN);
 #pragma unroll
-        for (uint32_t k = 0; k < RT_LIST_LEN / 4u; k++) dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+        for (uint32_t k = 0; k < LEN / 4u; k++) dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
     }
 }
 
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
     auto advance = [&]() {
         if (LIST && li != RT_LIST_SCANNING) {
             // cb holds the candidate itself while the list lasts
-            const uint32_t e = li < RT_LIST_LEN ? a.lists[(size_t)slot * RT_LIST_LEN + li] : RT_LIST_END;
+            const uint32_t e = li < a.list_len ? a.lists[(size_t)slot * a.list_len + li] : RT_LIST_END;
             if (e == RT_LIST_END) {
                 retire();
             } else if (e == RT_LIST_MORE) {

@@ -72,8 +72,9 @@ struct rthip_ctx {
     bool      tree = false;          // the extend stage walks the pyramid instead of scanning chunks
     void*     d_ptree = nullptr;     // spatial tree over the primitives' bounds, for the candidate lists
     bool      lists = false;         // candidates come from per-ray lists (k_cull_list)
-    uint32_t* cand_lists = nullptr;  // [queue slot][RT_LIST_LEN]
-    uint64_t  cand_cap = 0;
+    uint32_t* cand_lists = nullptr;  // [queue slot][list_len]
+    uint64_t  cand_cap = 0;          // in dwords
+    uint32_t  list_len = 0;          // entries per list of the uploaded scene
     void*     d_prims = nullptr;
     void*     d_texels = nullptr;
     void*     d_env = nullptr;
@@ -237,10 +238,10 @@ uint32_t frames_in_flight_limit(const rthip_ctx* c) {
     uint64_t budget = 48ull << 30;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const uint64_t held = (c->queue_mem ? c->queue_cap * 160ull : 0ull) + c->cand_cap * 4ull * RT_LIST_LEN;
+        const uint64_t held = (c->queue_mem ? c->queue_cap * 160ull : 0ull) + c->cand_cap * 4ull;
         budget = std::min<uint64_t>(budget, (free_b + held) / 2);
     }
-    const uint64_t per_slot = 160ull + (c->lists ? 4ull * RT_LIST_LEN : 0ull); // + a candidate list where the scene uses them
+    const uint64_t per_slot = 160ull + (c->lists ? 4ull * c->list_len : 0ull); // + a candidate list where the scene uses them
     while (want > 1 && (slots * want >= 0x7FFFFFFFull || c->n_pixels * want >= 0x7FFFFFFFull || slots * want * per_slot > budget)) want--;
     return want;
 }
@@ -367,6 +368,10 @@ template <bool DEEP> void shadow_extend_launch_t(ExtMode m, uint32_t grid, hipSt
     else if (m == EXT_TREE) hipLaunchKernelGGL((k_extend<false, DEEP, true, true, true>), dim3(grid), dim3(256), 0, st, ea);
     else if (m == EXT_SCAN) hipLaunchKernelGGL((k_extend<false, DEEP, true, true>), dim3(grid), dim3(256), 0, st, ea);
     else hipLaunchKernelGGL((k_extend<false, DEEP, false, true>), dim3(grid), dim3(256), 0, st, ea);
+}
+void cull_list_launch(uint32_t list_len, uint32_t grid, hipStream_t st, const CullListArgs& la) {
+    if (list_len == RT_LIST_LEN_LONG) hipLaunchKernelGGL((k_cull_list<RT_LIST_LEN_LONG>), dim3(grid), dim3(256), 0, st, la);
+    else hipLaunchKernelGGL((k_cull_list<RT_LIST_LEN>), dim3(grid), dim3(256), 0, st, la);
 }
 void shadow_extend_launch(bool deep, ExtMode m, uint32_t grid, hipStream_t st, const ExtArgs& ea) {
     if (deep) shadow_extend_launch_t<true>(m, grid, st, ea);
@@ -834,6 +839,13 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     if (lists) {
         HIP_TRY(c, upload(c->d_ptree, ptree.data(), sizeof(uint32_t) * ptree.size()));
         c->lists = true;
+        // longer lists pay where rays cross many bounds (8192 shuffled instances: 1476 -> 1777 Mrays/s)
+        // and cost where they do not (2048: 2669 -> 2623): the cull kernel's LDS and the bytes double
+        c->list_len = s->n_prims >= 4096u ? RT_LIST_LEN_LONG : RT_LIST_LEN;
+        if (const char* e = std::getenv("RTHIP_LIST_LEN")) { // tuning / test knob
+            const int v = std::atoi(e);
+            if (v == (int)RT_LIST_LEN || v == (int)RT_LIST_LEN_LONG) c->list_len = (uint32_t)v;
+        }
     }
     if (tree) {
         HIP_TRY(c, upload(c->d_tlas, tlas.data(), sizeof(float) * tlas.size()));
@@ -1024,12 +1036,12 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             HIP_TRY(c, hipMalloc((void**)&c->shadow_mem, sizeof(float4) * 4 * c->queue_cap));
             c->shadow_cap = c->queue_cap;
         }
-        if (ext_mode == EXT_LIST && c->cand_cap < c->queue_cap) {
+        if (ext_mode == EXT_LIST && c->cand_cap < c->queue_cap * c->list_len) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             free_dev_t(c->cand_lists);
             c->cand_cap = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->cand_lists, sizeof(uint32_t) * RT_LIST_LEN * c->queue_cap));
-            c->cand_cap = c->queue_cap;
+            HIP_TRY(c, hipMalloc((void**)&c->cand_lists, sizeof(uint32_t) * c->list_len * c->queue_cap));
+            c->cand_cap = c->queue_cap * c->list_len;
         }
         if (deep) { // stack levels beyond the LDS part: one dword column per thread of the extend grid
             const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi)) * ext_grid * 256;
@@ -1063,6 +1075,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             ea.tlas = static_cast<const float4*>(c->d_tlas);
             ea.tlas_dir = static_cast<const uint32_t*>(c->d_tlas_dir);
             ea.lists = c->cand_lists;
+            ea.list_len = c->list_len;
             ea.in = q[b & 1];
             ea.hits = c->hits;
             ea.spill = c->spill;
@@ -1095,7 +1108,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             if (ext_mode == EXT_LIST) {
                 CullListArgs la{static_cast<const float4*>(c->d_ptree), q[b & 1], c->cand_lists, c->ctrl + b};
                 StageTimer t(c, timing, RTHIP_STAGE_CULL);
-                hipLaunchKernelGGL(k_cull_list, dim3(shade_grid), dim3(256), 0, c->stream, la);
+                cull_list_launch(c->list_len, shade_grid, c->stream, la);
             }
 #ifdef RT_PROBE
             // diagnostic build only (tools/tail_probe.py): per-wave timestamps of this launch appended to $RTHIP_PROBE_FILE
@@ -1167,7 +1180,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 }
                 if (ext_mode == EXT_LIST) {
                     CullListArgs la{static_cast<const float4*>(c->d_ptree), sa.shadow, c->cand_lists, xa.count_in};
-                    hipLaunchKernelGGL(k_cull_list, dim3(shade_grid), dim3(256), 0, c->stream, la);
+                    cull_list_launch(c->list_len, shade_grid, c->stream, la);
                 }
                 shadow_extend_launch(deep, ext_mode, ext_grid, c->stream, xa);
                 ShadowArgs wa{};
