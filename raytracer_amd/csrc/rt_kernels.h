@@ -427,27 +427,32 @@ __global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
 // ------------------------------------------------------------------ candidate lists
 //
 // Long primitive lists whose order says nothing about space (neither the chunk scan nor the bounds
-// pyramid can skip anything then): a binary tree over the primitives' padded world bounds, built
+// pyramid can skip anything then): a 4-ary tree over the primitives' padded world bounds, built
 // at upload by median splits, is walked per ray in a kernel of its own, and the primitives whose
 // bound the ray meets -- the candidates of trace(), shader.wgsl:603-615 -- are written out SORTED
 // by index, so that the extend stage still visits them in the reference's order.  A list has 16
 // (or 32) entries: indices ascending, then RT_LIST_END; a ray with more candidates keeps all but
-// one entry's worth of its smallest, then RT_LIST_MORE, and the extend stage finds the rest by the chunk scan from the last listed
-// index on.  The walk has no distance bound and no order (every subtree the ray meets is visited).
-// Median splits make the tree complete but for its last level, so it is stored as a heap (node i
-// has the children 2i and 2i + 1, the root is 1) and walked without a stack: one bit per level
-// remembers that the right sibling of the path's node at that level is still to be visited, and
-// that sibling's index follows from the index of any of its nephews.  The list under construction
-// is an LDS column.
+// one entry's worth of its smallest, then RT_LIST_MORE, and the extend stage finds the rest by the
+// chunk scan from the last listed index on.  The walk has no distance bound and no order (every
+// subtree the ray meets is visited).  The tree is stored level by level (node j of level d has the
+// children 4j .. 4j + 3 of level d + 1; level d starts at record (4^d - 1) / 3) and walked without
+// a stack: four bits per level remember which siblings of the path's node at that level the ray
+// meets and has not visited yet, and the path's node at any level is the current index shifted
+// right.  The list under construction is an LDS column.
 #define RT_LIST_LEN 16u               // entries of a list; RT_LIST_LEN_LONG for the longest primitive lists (rthip_upload_scene picks)
 #define RT_LIST_LEN_LONG 32u
 #define RT_LIST_END 0xFFFFFFFFu
 #define RT_LIST_MORE 0xFFFFFFFEu
-#define RT_LIST_LEAF 0x80000000u      // descriptor of a tree child that is a primitive; an inner child's is 0
-#define RT_LIST_MAX_DEPTH 24u         // 16.7 M primitives; the heap has 2^depth records
+#define RT_LIST_LEAF 0x80000000u      // descriptor of a tree child that is a primitive
+#define RT_LIST_INNER 0u              // ... that is a node (its index follows from its parent's)
+#define RT_LIST_NONE 0xFFFFFFFFu      // ... that does not exist
+#define RT_LIST_MAX_DEPTH 12u         // inner levels 0 .. 11: 4^12 = 16.7 M primitives
+
+// first record of level d: (4^d - 1) / 3 = 0b0101..01 with d ones
+__host__ __device__ constexpr uint32_t rt_list_level_base(uint32_t d) { return 0x55555555u & ((1u << (2u * d)) - 1u); }
 
 struct CullListArgs {
-    const float4*   tree;   // heap of 64-byte records: the bounds of node i's two children (layout of the sibling pairs) + a descriptor each
+    const float4*   tree;   // 128-byte records: the bounds of a node's four children as six rows of four floats (min x, min y, min z, max x, max y, max z) + a descriptor each
     PathQueue       in;
     uint32_t*       lists;  // [slot][LEN]
     const uint32_t* count_in;
@@ -465,19 +470,24 @@ __global__ __launch_bounds__(256) void k_cull_list(CullListArgs a) {
         if (__float_as_uint(s1.w) == RT_NO_PIXEL) continue;
         f3 oi, idir;
         world_test_ray(F3(s0.x, s0.y, s0.z), F3(s0.w, s1.x, s1.y), oi, idir);
-        uint32_t cnt = 0, node = 1, depth = 0, pending = 0;
+        uint32_t cnt = 0, node = 0, depth = 0;
+        unsigned long long pending = 0; // nibble d: children of the path's node at level d - 1 still to visit
         bool dropped = false;
         for (;;) {
-            const float4* np = rec16(a.tree, node * 4u);
-            const float4 b0 = np[0], b1 = np[1], b2 = np[2];
-            const uint2 dsc = *reinterpret_cast<const uint2*>(np + 3);
-            const float bl[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y}, br[6] = {b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-            const bool hit[2] = {overlaps_world_box(oi, idir, bl), overlaps_world_box(oi, idir, br)};
-            const uint32_t child[2] = {dsc.x, dsc.y};
+            const float4* np = rec16(a.tree, (rt_list_level_base(depth) + node) * 8u);
+            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            const uint4 dsc = *reinterpret_cast<const uint4*>(np + 6);
+            const float b0[6] = {lx.x, ly.x, lz.x, hx.x, hy.x, hz.x}, b1[6] = {lx.y, ly.y, lz.y, hx.y, hy.y, hz.y};
+            const float b2[6] = {lx.z, ly.z, lz.z, hx.z, hy.z, hz.z}, b3[6] = {lx.w, ly.w, lz.w, hx.w, hy.w, hz.w};
+            const uint32_t child[4] = {dsc.x, dsc.y, dsc.z, dsc.w};
+            const bool hit[4] = {overlaps_world_box(oi, idir, b0), overlaps_world_box(oi, idir, b1),
+                                 overlaps_world_box(oi, idir, b2), overlaps_world_box(oi, idir, b3)};
+            uint32_t down = 0; // the inner children the ray meets
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (!hit[k] || !(child[k] & RT_LIST_LEAF)) continue;
-                // insert into the ascending list; the 17th candidate pushes the largest out
+            for (int k = 0; k < 4; k++) {
+                if (!hit[k] || child[k] == RT_LIST_NONE) continue;
+                if (child[k] == RT_LIST_INNER) { down |= 1u << k; continue; }
+                // a primitive: insert into the ascending list; one candidate too many pushes the largest out
                 const uint32_t p = child[k] & ~RT_LIST_LEAF;
                 if (cnt == LEN) {
                     dropped = true;
@@ -489,16 +499,18 @@ __global__ __launch_bounds__(256) void k_cull_list(CullListArgs a) {
                 cand[i * 256u] = p;
                 cnt++;
             }
-            const bool down_l = hit[0] && !(child[0] & RT_LIST_LEAF), down_r = hit[1] && !(child[1] & RT_LIST_LEAF);
-            if (down_l || down_r) {
+            if (down != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(down);
                 depth++;
-                if (down_l && down_r) pending |= 1u << depth; // the right child, at the new depth
-                node = 2u * node + (down_l ? 0u : 1u);
+                pending |= (unsigned long long)(down & (down - 1u)) << (4u * depth); // the others, at the new depth
+                node = 4u * node + k;
             } else {
-                if (pending == 0u) break;
-                const uint32_t level = 31u - (uint32_t)__builtin_clz(pending); // deepest sibling still to visit
-                pending &= ~(1u << level);
-                node = (node >> (depth - level)) | 1u; // the path's node at that level is a left child: its sibling
+                if (pending == 0ull) break;
+                const uint32_t level = (63u - (uint32_t)__builtin_clzll(pending)) >> 2; // deepest level with a sibling to visit
+                const uint32_t sib = (uint32_t)(pending >> (4u * level)) & 15u;
+                const uint32_t k = (uint32_t)__builtin_ctz(sib);
+                pending &= ~(1ull << (4u * level + k));
+                node = ((node >> (2u * (depth - level))) & ~3u) | k; // the path's node at that level, its sibling k
                 depth = level;
             }
         }
