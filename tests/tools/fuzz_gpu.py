@@ -47,6 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=48, help="single rays per case through rthip_trace_rays")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
@@ -72,8 +73,32 @@ def main():
             c.reset_counters()
             c.render(first, n, 1, p)
             got = dict(accum=c.read_accum(), counters=c.counters(), **c.read_taps())
+            # single rays as well: random ones, and axis-parallel ones (zero direction components make the
+            # reciprocal infinite: the slab tests then run on infinities, shader.wgsl:415-438)
+            v = a["tris"]["v"][:, :, :3].reshape(-1, 3)
+            tr = np.asarray(a["prims"]["transform"], np.float32).reshape(-1, 16)[:, 12:15] # translations (column-major)
+            lo, hi = tr.min(0) + v.min(0) - 1.0, tr.max(0) + v.max(0) + 1.0
+            nq = args.rays
+            ro = rng.uniform(lo, hi, (nq, 3)).astype(np.float32)
+            rd = rng.normal(size=(nq, 3)).astype(np.float32)
+            rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+            for k in range(0, nq, 3):
+                ax = int(rng.integers(0, 3))
+                rd[k] = 0.0
+                rd[k, ax] = float(rng.choice([-1.0, 1.0]))
+                if k % 2 == 0:
+                    ro[k] = np.round(ro[k])      # origins on round coordinates: on box faces and triangle planes of the procedural scenes
+            pq = device.default_params(stack_depth=p.stack_depth)
+            q = c.trace_rays(ro, rd, None, pq)
         finally:
             c.close()
+        sc_o = oracle_scene(a)
+        op_q = oracle_params(pq)
+        ray_bad = 0
+        for k in range(nq):
+            tri, prim, tt, _ = orc.trace_ray(sc_o, ro[k], rd[k], op_q, 0)
+            if q["tri"][k] != tri or (tri >= 0 and (q["prim"][k] != prim or q["t"][k] != np.float32(tt))):
+                ray_bad += 1
         ref = orc.render(oracle_scene(a), u, oracle_params(p), first, n, 1, taps=True, n_threads=threads)
         npx = res[0] * res[1]
         tri_ok = float((got["tri"] == ref["tri"]).mean())
@@ -88,11 +113,11 @@ def main():
         # The PSNR is printed for information: at 1-3 samples per pixel a handful of such pixels set it.
         db = psnr(tonemapped(got["accum"]), tonemapped(ref["accum"]))
         fail = ((1.0 - tri_ok) * npx > max(2, 1e-3 * npx) or (1.0 - seed_ok) * npx > max(3, 4e-3 * npx) or img_bad > max(3, 3e-3 * npx)
-                or not alpha_ok or cnt_bad)
+                or not alpha_ok or cnt_bad or ray_bad)
         bad += bool(fail)
         print(f"{'FAIL' if fail else 'ok  '} case {case}: {kind} prims={a['prims'].shape[0]} walk={got_walk} res={res} bounces={p.max_bounces} "
               f"p={p.term_prob} stack={p.stack_depth} sun={p.enable_sun} frames={first}+{n}: tri {tri_ok:.5f} seed {seed_ok:.5f} "
-              f"img_bad {img_bad} psnr {db:.1f} alpha {alpha_ok} counters {cnt_bad or 'ok'}", flush=True)
+              f"img_bad {img_bad} psnr {db:.1f} alpha {alpha_ok} counters {cnt_bad or 'ok'} rays_bad {ray_bad}", flush=True)
     print(f"{args.cases - bad} of {args.cases} cases agree")
     return 1 if bad else 0
 
