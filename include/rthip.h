@@ -153,8 +153,8 @@ int rthip_frames_in_flight(rthip_ctx* ctx, uint32_t* n_frames);
  * bit mask per ray; RTHIP_WALK_SCAN = chunks of 128 primitives scanned wave by wave;
  * RTHIP_WALK_PYRAMID = per-ray walk of an 8-ary pyramid of bounds over the primitive list, chosen
  * for long lists whose neighbours are neighbours in space; RTHIP_WALK_LIST = per-ray candidate lists,
- * sorted by index, from a spatial tree over the primitives' bounds (rthip_render; ray queries of such
- * a scene use the scan), chosen for long lists in an order that says nothing about space.  The
+ * sorted by index, from a spatial tree over the primitives' bounds (rthip_trace_rays_noalloc uses
+ * the scan for such a scene), chosen for long lists in an order that says nothing about space.  The
  * result of a render does not depend on it.  No counterpart upstream. */
 #define RTHIP_WALK_MASK 0
 #define RTHIP_WALK_SCAN 1

@@ -123,6 +123,8 @@ struct rthip_ctx {
     float4*   tr_q = nullptr;
     float4*   tr_hits = nullptr;
     uint64_t  tr_cap = 0;
+    uint32_t* tr_lists = nullptr;    // candidate lists of the rays of rthip_trace_rays (scenes that use them)
+    uint64_t  tr_lists_cap = 0;      // in dwords
     uint32_t* resolve_out = nullptr;
     uint64_t  resolve_cap = 0;
 
@@ -434,7 +436,7 @@ void rthip_destroy(rthip_ctx* c) {
     free_frame_buffers(c);
     free_dev_t(c->ctrl);
     free_dev_t(c->d_counters);
-    free_dev_t(c->tr_q); free_dev_t(c->tr_hits); free_dev_t(c->resolve_out);
+    free_dev_t(c->tr_q); free_dev_t(c->tr_hits); free_dev_t(c->tr_lists); free_dev_t(c->resolve_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1286,7 +1288,7 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
     const bool timing = (P.flags & RTHIP_FLAG_TIMING) != 0;
     const bool multi = c->sc.n_chunks > 1u;
-    const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : EXT_SCAN);
+    const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : (c->lists ? EXT_LIST : EXT_SCAN));
     const bool deep = P.stack_depth > rt_lds_levels(multi);
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
@@ -1303,10 +1305,20 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
             c->spill_words = words;
         }
     }
+    if (ext_mode == EXT_LIST && c->tr_lists_cap < n * c->list_len) {
+        (void)hipStreamSynchronize(c->stream);
+        free_dev_t(c->tr_lists);
+        c->tr_lists_cap = 0;
+        e = hipMalloc((void**)&c->tr_lists, sizeof(uint32_t) * n * c->list_len);
+        if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
+        c->tr_lists_cap = n * c->list_len;
+    }
     ExtArgs ea{};
     ea.sc = c->sc;
     ea.tlas = static_cast<const float4*>(c->d_tlas);
     ea.tlas_dir = static_cast<const uint32_t*>(c->d_tlas_dir);
+    ea.lists = c->tr_lists;
+    ea.list_len = c->list_len;
     ea.in.s0 = d_q; ea.in.s1 = d_q + n; ea.in.s2 = d_q; ea.in.s3 = d_q;
     ea.hits = d_hits;
     ea.spill = c->spill;
@@ -1326,6 +1338,11 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
         ca.count_in = d_ctl;
         StageTimer tm(c, timing, RTHIP_STAGE_CULL);
         hipLaunchKernelGGL(k_cull, dim3((uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n + 255) / 256)), dim3(256), 0, c->stream, ca);
+    }
+    if (ext_mode == EXT_LIST) {
+        CullListArgs la{static_cast<const float4*>(c->d_ptree), ea.in, c->tr_lists, d_ctl};
+        StageTimer tm(c, timing, RTHIP_STAGE_CULL);
+        cull_list_launch(c->list_len, (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n + 255) / 256), c->stream, la);
     }
     {
         StageTimer tm(c, timing, RTHIP_STAGE_EXTEND);

@@ -319,7 +319,7 @@ def test_ten_thousand_primitives_use_super_chunks(ctx, monkeypatch, walk):
     assert a["prims"].shape[0] == 10368
     if walk == "scan":
         monkeypatch.setenv("RTHIP_TREE_MIN_PRIMS", "4000000000")
-    elif walk == "list":   # per-ray candidate lists in the frame below; the single rays of such a scene take the scan
+    elif walk == "list":   # per-ray candidate lists, for the single rays and the frame below
         monkeypatch.setenv("RTHIP_CANDIDATE_WALK", "list")
     ctx.upload_scene(a)
     assert ctx.candidate_walk() == walk

@@ -57,7 +57,7 @@ def test_noalloc_equals_trace_rays_twice_in_a_row(scene_name):
     elif scene_name == "instanced":     # more than 128 primitives: the in-kernel candidate scan
         s, params, sizes = procedural.terrain_scene(tiles=10, n=12, env_size=(64, 32), instanced=True), device.default_params(), (device.NOALLOC_MAX_RAYS, 64)
     else:                               # a long primitive list: the walk of the bounds pyramid, with a deep stack as well;
-                                        # in shuffled order a render would use per-ray lists, ray queries take the scan
+                                        # in shuffled order renders and rthip_trace_rays use per-ray lists, the entry point without allocations the scan
         s, params, sizes = (procedural.terrain_scene(tiles=18, n=8, env_size=(64, 32), instanced=True, shuffled=scene_name.endswith("lists")),
                             device.default_params(stack_depth=40), (90000, 1000))
     a = s.arrays()
