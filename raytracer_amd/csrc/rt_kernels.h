@@ -556,11 +556,15 @@ __device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, fl
 #ifndef RT_LDS_LEVELS_SINGLE
 #define RT_LDS_LEVELS_SINGLE 13u
 #endif
+#ifndef RT_LDS_LEVELS_MULTI
 #define RT_LDS_LEVELS_MULTI 16u
+#endif
 #ifndef RT_EXTEND_WAVES_SINGLE
 #define RT_EXTEND_WAVES_SINGLE 8
 #endif
+#ifndef RT_EXTEND_WAVES_MULTI
 #define RT_EXTEND_WAVES_MULTI 7
+#endif
 #ifndef RT_EXTEND_WAVES_TREE
 #define RT_EXTEND_WAVES_TREE 7
 #endif
