@@ -66,6 +66,10 @@ typedef struct {
 #define RTHIP_FLAG_COUNTERS 1u   /* maintain rthip_counters (small cost)                       */
 #define RTHIP_FLAG_TAPS     2u   /* record primary hits + final seeds of the first frame       */
 #define RTHIP_FLAG_TIMING   4u   /* bracket every stage launch with HIP events (rthip_timing)  */
+#define RTHIP_FLAG_STAGED   8u   /* calls of one to three frames too go through the staged pipeline
+                                    (generate / cull / extend / shade launches per bounce) instead of
+                                    the single launch in which a lane owns a whole path; the result
+                                    is the same bit for bit                                       */
 
 #define RTHIP_MAX_STACK_DEPTH 64u
 
@@ -98,7 +102,8 @@ typedef struct {
 #define RTHIP_STAGE_ACCUMULATE 4 /* frame-ordered sum of the per-frame results into screen  */
 #define RTHIP_STAGE_SHADOW   5   /* enable_sun only: the shadow rays of a bounce             */
 #define RTHIP_STAGE_CULL     6   /* candidate primitives per ray (scenes of up to 128 primitives) */
-#define RTHIP_NUM_STAGES     7
+#define RTHIP_STAGE_PATH     7   /* calls of one to three frames: the whole of cs_main in one launch */
+#define RTHIP_NUM_STAGES     8
 
 typedef struct {
     double   ms[RTHIP_NUM_STAGES];        /* summed kernel time per stage, HIP events       */

@@ -80,15 +80,15 @@ struct GenArgs {
 // the index of its private accumulation slot.
 #define RT_NO_PIXEL 0xFFFFFFFFu
 
-__global__ __launch_bounds__(256) void k_generate(GenArgs a) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t per_frame = a.n_tiles * 64u;
+// The camera path of queue slot gid: which pixel of which frame it renders, its random state after
+// the four camera draws, and its ray (shader.wgsl:895-897, 741-779).  False for a lane of an edge
+// tile that falls outside the image.
+__device__ __forceinline__ bool camera_path(const GenArgs& a, uint32_t gid, f3& origin, f3& dir, uint32_t& seed, uint32_t& pix) {
     // queue order: tile-major, the frames of a tile next to each other, so that neighbouring
     // runs of 64 slots hold rays through the same pixels (and stay neighbours through the
     // order-preserving compaction of the later bounces)
     const uint32_t run = gid >> 6, l = gid & 63u;
     const uint32_t tile = run / a.n_frames, fs = run - tile * a.n_frames;
-    if (tile >= a.n_tiles) return;
     // Which pixel of which tile lane l of the run renders.  A whole tile per run keeps a wave's
     // rays together (they walk the same nodes), and with it their cost: the rays of a tile full of
     // foliage all take several times the average, and the wave that holds them ends long after the
@@ -107,37 +107,48 @@ __global__ __launch_bounds__(256) void k_generate(GenArgs a) {
     }
     const uint32_t px = (t2 % a.tiles_x) * 8u + lx;
     const uint32_t py = (t2 / a.tiles_x) * 8u + ly;
-    const bool valid = px < a.res_x && py < a.res_y;
+    if (!(px < a.res_x && py < a.res_y)) return false;
+    seed = hash21(hash21(px, py), a.first_frame + fs * a.frame_stride); // shader.wgsl:895
+    // camera_ray, shader.wgsl:741-779 (basis vectors and fov factor are per-frame constants)
+    const f3 origin0 = F3(a.origin[0], a.origin[1], a.origin[2]);
+    const f3 forward = F3(a.forward[0], a.forward[1], a.forward[2]);
+    const f3 right = F3(a.right[0], a.right[1], a.right[2]);
+    const f3 up = F3(a.up[0], a.up[1], a.up[2]);
+    f3 pixel_pos = origin0 + forward;
+    const float rx = rnd(seed);
+    const float ry = rnd(seed);
+    const float aax = (float)px + rx, aay = (float)py + ry;
+    const float resx = (float)a.res_x, resy = (float)a.res_y;
+    pixel_pos = pixel_pos + ((right * (aax / resx - 0.5f)) * a.fov_factor) * a.aspect;
+    pixel_pos = pixel_pos + (up * (0.5f - aay / resy)) * a.fov_factor;
+    dir = normalize(pixel_pos - origin0);
+    const float theta = rnd(seed) * 2.0f * RT_PI; // rand_disk, shader.wgsl:669-673
+    const float radius = sqrtf(rnd(seed));
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    const float ax = a.aperture_radius * (radius * cs);
+    const float ay = a.aperture_radius * (radius * sn);
+    origin = origin0 + right * ax;
+    origin = origin + up * ay;
+    pixel_pos = pixel_pos + dir * (a.focus - 1.0f);
+    dir = normalize(pixel_pos - origin);
+    pix = fs * a.n_pixels + px + a.res_x * py;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_generate(GenArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_frame = a.n_tiles * 64u;
+    if ((gid >> 6) / a.n_frames >= a.n_tiles) return;
     if (gid == 0) *a.count_out = per_frame * a.n_frames;
 
     float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, __uint_as_float(RT_NO_PIXEL));
+    f3 origin, dir;
+    uint32_t seed, pix;
+    const bool valid = camera_path(a, gid, origin, dir, seed, pix);
     if (valid) {
-        uint32_t seed = hash21(hash21(px, py), a.first_frame + fs * a.frame_stride); // shader.wgsl:895
-        // camera_ray, shader.wgsl:741-779 (basis vectors and fov factor are per-frame constants)
-        const f3 origin0 = F3(a.origin[0], a.origin[1], a.origin[2]);
-        const f3 forward = F3(a.forward[0], a.forward[1], a.forward[2]);
-        const f3 right = F3(a.right[0], a.right[1], a.right[2]);
-        const f3 up = F3(a.up[0], a.up[1], a.up[2]);
-        f3 pixel_pos = origin0 + forward;
-        const float rx = rnd(seed);
-        const float ry = rnd(seed);
-        const float aax = (float)px + rx, aay = (float)py + ry;
-        const float resx = (float)a.res_x, resy = (float)a.res_y;
-        pixel_pos = pixel_pos + ((right * (aax / resx - 0.5f)) * a.fov_factor) * a.aspect;
-        pixel_pos = pixel_pos + (up * (0.5f - aay / resy)) * a.fov_factor;
-        f3 dir = normalize(pixel_pos - origin0);
-        const float theta = rnd(seed) * 2.0f * RT_PI; // rand_disk, shader.wgsl:669-673
-        const float radius = sqrtf(rnd(seed));
-        float sn, cs;
-        sincosf(theta, &sn, &cs);
-        const float ax = a.aperture_radius * (radius * cs);
-        const float ay = a.aperture_radius * (radius * sn);
-        f3 origin = origin0 + right * ax;
-        origin = origin + up * ay;
-        pixel_pos = pixel_pos + dir * (a.focus - 1.0f);
-        dir = normalize(pixel_pos - origin);
         s0 = make_float4(origin.x, origin.y, origin.z, dir.x);
-        s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(fs * a.n_pixels + px + a.res_x * py));
+        s1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(pix));
     }
     a.out.s0[gid] = s0;
     a.out.s1[gid] = s1; // throughput (1) and lighting (0) are implied for camera paths
@@ -1288,6 +1299,155 @@ __device__ __forceinline__ f3 linear_rgb(const float* lut, uint32_t x) {
     return F3(lut[(x >> 24) & 255u], lut[(x >> 16) & 255u], lut[(x >> 8) & 255u]);
 }
 
+// What the bounce loop does with a traced ray (shader.wgsl:898-914), for one path: a miss gathers
+// the environment and ends the path, the termination draw ends it (with the sun option: after
+// sending a shadow ray), otherwise handle_surface_hit_brdf continues it.
+#define RT_PATH_END    0   // lit is the path's result
+#define RT_PATH_BOUNCE 1   // origin, dir, thr, lit, seed describe the next segment
+#define RT_PATH_SHADOW 2   // SUN only: origin, dir are the shadow ray, sun_term what it carries, lit the light gathered so far
+struct ShadeCounts { unsigned long long shade = 0, miss = 0, kill = 0, texel = 0; };
+
+template <bool COUNT, bool SUN>
+__device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* lin_lut, float term_prob, f3& origin, f3& dir, f3& thr, f3& lit,
+                                             uint32_t& seed, int32_t tri, uint32_t prim, float hit_t, f3& sun_term, ShadeCounts& cnt) {
+    if (tri < 0) { // handle_miss / sky / sample_env_map, shader.wgsl:883-885, 691-702
+        if (COUNT) cnt.miss++;
+        const float u = atan2f(dir.y, dir.x) / (RT_PI * 2.0f) + 0.5f;
+        const float v = asinf(-dir.z) / RT_PI + 0.5f;
+        uint32_t ex = f2u(u * (float)sc.env_w), ey = f2u(v * (float)sc.env_h);
+        if (ex >= sc.env_w) ex = sc.env_w - 1u;
+        if (ey >= sc.env_h) ey = sc.env_h - 1u;
+        const float4 e = sc.env[(size_t)ey * sc.env_w + ex];
+        lit = lit + thr * F3(e.x * 1.0f, e.y * 1.0f, e.z * 1.0f);
+        return RT_PATH_END;
+    }
+    if (rnd(seed) < term_prob) { // shader.wgsl:907-909
+        if (COUNT) cnt.kill++;
+        thr = thr / term_prob;
+        if (SUN) {
+            // The sun block the reference keeps commented out (shader.wgsl:916-937), as an
+            // option: a terminated path sends one shadow ray towards the sun.
+            const PrimitiveD& pr = sc.prims[prim];
+            const float* im = pr.inv_transform;
+            const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
+                             (im[2] * dir.x + im[6] * dir.y) + im[10] * dir.z);
+            const f3 ld = normalize(td);
+            const float4 a1 = sc.tris[3 * (size_t)tri + 1], a2 = sc.tris[3 * (size_t)tri + 2];
+            f3 ng = normalize(cross(F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z)));
+            ng = ng * (-sign11(dot(ng, ld)));
+            const f3 n_geo = normalize(F3((im[0] * ng.x + im[1] * ng.y) + im[2] * ng.z, (im[4] * ng.x + im[5] * ng.y) + im[6] * ng.z,
+                                          (im[8] * ng.x + im[9] * ng.y) + im[10] * ng.z));
+            const float sl = sqrtf((0.5f * 0.5f + 0.4f * 0.4f) + 1.49f * 1.49f); // TO_SUN_DIR, shader.wgsl:20-24
+            const f3 sun = F3(0.5f / sl, 0.4f / sl, 1.49f / sl);
+            const f3 so = origin + (dir * hit_t + n_geo * 0.0001f);
+            const f3 sd = normalize(sun + rand_sphere(seed) * 0.01f);
+            const float lambert = fmaxf(dot(sun, n_geo), 0.0f) / RT_PI;
+            if (lambert > 0.0f) {
+                sun_term = ((thr * F3(1.0f * 5.0f, 0.5f * 5.0f, 0.3f * 5.0f)) * 12.0f) * lambert;
+                origin = so;
+                dir = sd;
+                return RT_PATH_SHADOW;
+            }
+        }
+        return RT_PATH_END;
+    }
+    thr = thr / (1.0f - term_prob);
+    // ---- handle_surface_hit_brdf, shader.wgsl:803-881
+    if (COUNT) cnt.shade++;
+    const PrimitiveD& pr = sc.prims[prim];
+    const float* im = pr.inv_transform;
+    // the primitive-space ray and the geometric normal, as trace() recomputes them
+    // for the winning triangle (shader.wgsl:617-625, 376-412)
+    const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
+                     (im[2] * dir.x + im[6] * dir.y) + im[10] * dir.z);
+    const f3 ld = normalize(td);
+    const f3 lo = F3(((im[0] * origin.x + im[4] * origin.y) + im[8] * origin.z) + im[12],
+                     ((im[1] * origin.x + im[5] * origin.y) + im[9] * origin.z) + im[13],
+                     ((im[2] * origin.x + im[6] * origin.y) + im[10] * origin.z) + im[14]);
+    const float4 a0 = sc.tris[3 * (size_t)tri], a1 = sc.tris[3 * (size_t)tri + 1], a2 = sc.tris[3 * (size_t)tri + 2];
+    const f3 p0 = F3(a0.x, a0.y, a0.z), e1 = F3(a1.x, a1.y, a1.z), e2 = F3(a2.x, a2.y, a2.z);
+    f3 ng = normalize(cross(e1, e2));
+    ng = ng * (-sign11(dot(ng, ld)));
+    float bu = 0.333f, bv = 0.333f, b0 = 0.333f;
+    {
+        float u, v;
+        const float t = hit_tri(lo, ld, p0, e1, e2, u, v);
+        if (t >= 0.0f) { b0 = (1.0f - u) - v; bu = u; bv = v; }
+    }
+    // transform_normal, shader.wgsl:585-587
+    const f3 n_geo = normalize(F3((im[0] * ng.x + im[1] * ng.y) + im[2] * ng.z, (im[4] * ng.x + im[5] * ng.y) + im[6] * ng.z,
+                                  (im[8] * ng.x + im[9] * ng.y) + im[10] * ng.z));
+    (void)rnd(seed); // shader.wgsl:804
+    origin = origin + dir * hit_t;
+    origin = origin + n_geo * 0.001f;
+
+    // tri_ext_interpolate, shader.wgsl:229-253
+    const float4* ex = sc.exts + 6 * (size_t)tri;
+    const float4 v0a = ex[0], v0b = ex[1], v1a = ex[2], v1b = ex[3], v2a = ex[4], v2b = ex[5];
+    float tc0x = 0.0f, tc0y = 0.0f, tc1x = 0.0f, tc1y = 0.0f;
+    tc0x += b0 * v0a.x; tc0y += b0 * v0a.y; tc1x += b0 * v0a.z; tc1y += b0 * v0a.w;
+    f3 sn = F3(0.0f, 0.0f, 0.0f) + unpack_oct(v0b.x, v0b.y) * b0;
+    tc0x += bu * v1a.x; tc0y += bu * v1a.y; tc1x += bu * v1a.z; tc1y += bu * v1a.w;
+    sn = sn + unpack_oct(v1b.x, v1b.y) * bu;
+    tc0x += bv * v2a.x; tc0y += bv * v2a.y; tc1x += bv * v2a.z; tc1y += bv * v2a.w;
+    sn = sn + unpack_oct(v2b.x, v2b.y) * bv;
+    sn = normalize(sn);
+    if (length(sn) > 0.001f) { // shader.wgsl:816-824
+        const f3 nn = normalize(sn);
+        sn = normalize(F3((im[0] * nn.x + im[1] * nn.y) + im[2] * nn.z, (im[4] * nn.x + im[5] * nn.y) + im[6] * nn.z,
+                          (im[8] * nn.x + im[9] * nn.y) + im[10] * nn.z));
+        if (dot(sn, n_geo) < 0.0f) sn = neg(sn);
+    } else {
+        sn = n_geo;
+    }
+
+    const MaterialD& m = pr.material;
+    f3 albedo = F3(m.albedo_factor[0], m.albedo_factor[1], m.albedo_factor[2]);
+    if (m.albedo.size != 0u) {
+        const bool s1set = m.albedo_texcoord >= 1u;
+        if (COUNT) cnt.texel++;
+        albedo = albedo * linear_rgb(lin_lut, fetch_texel(sc, m.albedo.offset, m.albedo.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+    } else {
+        albedo = albedo * F3(0.01f, 0.02f, 0.03f);
+    }
+    f3 emissive = F3(m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2]);
+    if (m.emissive.size != 0u) {
+        const bool s1set = m.emissive_texcoord >= 1u;
+        if (COUNT) cnt.texel++;
+        emissive = emissive * linear_rgb(lin_lut, fetch_texel(sc, m.emissive.offset, m.emissive.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+    }
+    float metallic_chance = m.metallic_factor;
+    float roughness = m.roughness_factor;
+    if (m.metallic_roughness.size != 0u) {
+        const bool s1set = m.metal_r_texcoord >= 1u;
+        if (COUNT) cnt.texel++;
+        const f3 mr = unpack_rgb(fetch_texel(sc, m.metallic_roughness.offset, m.metallic_roughness.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+        metallic_chance = mr.z;
+        roughness *= mr.y;
+    }
+
+    const bool metal = rnd(seed) < metallic_chance;
+    const float f0x = metal ? albedo.x : 0.04f;
+    f3 hemi = rand_sphere(seed); // rand_hemisphere, shader.wgsl:675-681
+    if (dot(hemi, sn) < 0.0f) hemi = hemi * -1.0f;
+    const float mt = roughness * roughness * 0.8f;
+    const f3 mn = normalize(F3(mixf(sn.x, hemi.x, mt), mixf(sn.y, hemi.y, mt), mixf(sn.z, hemi.z, mt)));
+    const float pw = powf(1.0f - dot(mn, neg(dir)), 5.0f); // fresnel_schlick, shader.wgsl:791-793
+    const float fresnel_x = f0x + (1.0f - f0x) * pw;
+    const bool specular = rnd(seed) < fresnel_x;
+
+    lit = lit + emissive * thr;
+    if (!specular || metal) thr = thr * albedo;
+    if (specular || metal) {
+        f3 nd = dir - mn * (2.0f * dot(mn, dir)); // reflect
+        if (dot(nd, sn) < 0.0f) nd = normalize(nd - sn * dot(nd, sn)); // project_to_hemisphere
+        dir = nd;
+    } else {
+        dir = normalize(sn + rand_sphere(seed)); // sample_lambert, shader.wgsl:781-785
+    }
+    return RT_PATH_BOUNCE;
+}
+
 template <bool COUNT, bool SUN>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     __shared__ uint32_t scratch[8];
@@ -1298,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const uint32_t n = *a.count_in;
     const uint32_t n_pad = (n + 255u) & ~255u; // whole blocks stay in the loop together
     const uint32_t stride = gridDim.x * blockDim.x;
-    unsigned long long c_shade = 0, c_miss = 0, c_kill = 0, c_texel = 0;
+    ShadeCounts cnt;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_pad; slot += stride) {
         bool survive = false, to_shadow = false;
         float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
@@ -1315,143 +1475,15 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             const int32_t tri = __float_as_int(h.y);
             const uint32_t primw = __float_as_uint(h.z);
             const bool overflow = (primw >> 31) != 0u;
-            const uint32_t prim = primw & 0x7FFFFFFFu;
-            const float hit_t = h.x;
-
-            if (tri < 0) { // handle_miss / sky / sample_env_map, shader.wgsl:883-885, 691-702
-                if (COUNT) c_miss++;
-                const float u = atan2f(dir.y, dir.x) / (RT_PI * 2.0f) + 0.5f;
-                const float v = asinf(-dir.z) / RT_PI + 0.5f;
-                uint32_t ex = f2u(u * (float)a.sc.env_w), ey = f2u(v * (float)a.sc.env_h);
-                if (ex >= a.sc.env_w) ex = a.sc.env_w - 1u;
-                if (ey >= a.sc.env_h) ey = a.sc.env_h - 1u;
-                const float4 e = a.sc.env[(size_t)ey * a.sc.env_w + ex];
-                lit = lit + thr * F3(e.x * 1.0f, e.y * 1.0f, e.z * 1.0f);
-            } else if (rnd(seed) < a.term_prob) { // shader.wgsl:907-909
-                if (COUNT) c_kill++;
-                thr = thr / a.term_prob;
-                if (SUN) {
-                    // The sun block the reference keeps commented out (shader.wgsl:916-937), as an
-                    // option: a terminated path sends one shadow ray towards the sun.
-                    const PrimitiveD& pr = a.sc.prims[prim];
-                    const float* im = pr.inv_transform;
-                    const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
-                                     (im[2] * dir.x + im[6] * dir.y) + im[10] * dir.z);
-                    const f3 ld = normalize(td);
-                    const float4 a1 = a.sc.tris[3 * (size_t)tri + 1], a2 = a.sc.tris[3 * (size_t)tri + 2];
-                    f3 ng = normalize(cross(F3(a1.x, a1.y, a1.z), F3(a2.x, a2.y, a2.z)));
-                    ng = ng * (-sign11(dot(ng, ld)));
-                    const f3 n_geo = normalize(F3((im[0] * ng.x + im[1] * ng.y) + im[2] * ng.z, (im[4] * ng.x + im[5] * ng.y) + im[6] * ng.z,
-                                                  (im[8] * ng.x + im[9] * ng.y) + im[10] * ng.z));
-                    const float sl = sqrtf((0.5f * 0.5f + 0.4f * 0.4f) + 1.49f * 1.49f); // TO_SUN_DIR, shader.wgsl:20-24
-                    const f3 sun = F3(0.5f / sl, 0.4f / sl, 1.49f / sl);
-                    const f3 so = origin + (dir * hit_t + n_geo * 0.0001f);
-                    const f3 sd = normalize(sun + rand_sphere(seed) * 0.01f);
-                    const float lambert = fmaxf(dot(sun, n_geo), 0.0f) / RT_PI;
-                    if (lambert > 0.0f) {
-                        const f3 term = ((thr * F3(1.0f * 5.0f, 0.5f * 5.0f, 0.3f * 5.0f)) * 12.0f) * lambert;
-                        to_shadow = true;
-                        o0 = make_float4(so.x, so.y, so.z, sd.x);
-                        o1 = make_float4(sd.y, sd.z, __uint_as_float(seed), __uint_as_float(pix));
-                        o2 = make_float4(term.x, term.y, term.z, overflow ? 1.0f : 0.0f);
-                        o3 = make_float4(lit.x, lit.y, lit.z, 0.0f);
-                    }
-                }
-            } else {
-                thr = thr / (1.0f - a.term_prob);
-                // ---- handle_surface_hit_brdf, shader.wgsl:803-881
-                if (COUNT) c_shade++;
-                const PrimitiveD& pr = a.sc.prims[prim];
-                const float* im = pr.inv_transform;
-                // the primitive-space ray and the geometric normal, as trace() recomputes them
-                // for the winning triangle (shader.wgsl:617-625, 376-412)
-                const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
-                                 (im[2] * dir.x + im[6] * dir.y) + im[10] * dir.z);
-                const f3 ld = normalize(td);
-                const f3 lo = F3(((im[0] * origin.x + im[4] * origin.y) + im[8] * origin.z) + im[12],
-                                 ((im[1] * origin.x + im[5] * origin.y) + im[9] * origin.z) + im[13],
-                                 ((im[2] * origin.x + im[6] * origin.y) + im[10] * origin.z) + im[14]);
-                const float4 a0 = a.sc.tris[3 * (size_t)tri], a1 = a.sc.tris[3 * (size_t)tri + 1], a2 = a.sc.tris[3 * (size_t)tri + 2];
-                const f3 p0 = F3(a0.x, a0.y, a0.z), e1 = F3(a1.x, a1.y, a1.z), e2 = F3(a2.x, a2.y, a2.z);
-                f3 ng = normalize(cross(e1, e2));
-                ng = ng * (-sign11(dot(ng, ld)));
-                float bu = 0.333f, bv = 0.333f, b0 = 0.333f;
-                {
-                    float u, v;
-                    const float t = hit_tri(lo, ld, p0, e1, e2, u, v);
-                    if (t >= 0.0f) { b0 = (1.0f - u) - v; bu = u; bv = v; }
-                }
-                // transform_normal, shader.wgsl:585-587
-                const f3 n_geo = normalize(F3((im[0] * ng.x + im[1] * ng.y) + im[2] * ng.z, (im[4] * ng.x + im[5] * ng.y) + im[6] * ng.z,
-                                              (im[8] * ng.x + im[9] * ng.y) + im[10] * ng.z));
-                (void)rnd(seed); // shader.wgsl:804
-                origin = origin + dir * hit_t;
-                origin = origin + n_geo * 0.001f;
-
-                // tri_ext_interpolate, shader.wgsl:229-253
-                const float4* ex = a.sc.exts + 6 * (size_t)tri;
-                const float4 v0a = ex[0], v0b = ex[1], v1a = ex[2], v1b = ex[3], v2a = ex[4], v2b = ex[5];
-                float tc0x = 0.0f, tc0y = 0.0f, tc1x = 0.0f, tc1y = 0.0f;
-                tc0x += b0 * v0a.x; tc0y += b0 * v0a.y; tc1x += b0 * v0a.z; tc1y += b0 * v0a.w;
-                f3 sn = F3(0.0f, 0.0f, 0.0f) + unpack_oct(v0b.x, v0b.y) * b0;
-                tc0x += bu * v1a.x; tc0y += bu * v1a.y; tc1x += bu * v1a.z; tc1y += bu * v1a.w;
-                sn = sn + unpack_oct(v1b.x, v1b.y) * bu;
-                tc0x += bv * v2a.x; tc0y += bv * v2a.y; tc1x += bv * v2a.z; tc1y += bv * v2a.w;
-                sn = sn + unpack_oct(v2b.x, v2b.y) * bv;
-                sn = normalize(sn);
-                if (length(sn) > 0.001f) { // shader.wgsl:816-824
-                    const f3 nn = normalize(sn);
-                    sn = normalize(F3((im[0] * nn.x + im[1] * nn.y) + im[2] * nn.z, (im[4] * nn.x + im[5] * nn.y) + im[6] * nn.z,
-                                      (im[8] * nn.x + im[9] * nn.y) + im[10] * nn.z));
-                    if (dot(sn, n_geo) < 0.0f) sn = neg(sn);
-                } else {
-                    sn = n_geo;
-                }
-
-                const MaterialD& m = pr.material;
-                f3 albedo = F3(m.albedo_factor[0], m.albedo_factor[1], m.albedo_factor[2]);
-                if (m.albedo.size != 0u) {
-                    const bool s1set = m.albedo_texcoord >= 1u;
-                    if (COUNT) c_texel++;
-                    albedo = albedo * linear_rgb(lin_lut, fetch_texel(a.sc, m.albedo.offset, m.albedo.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
-                } else {
-                    albedo = albedo * F3(0.01f, 0.02f, 0.03f);
-                }
-                f3 emissive = F3(m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2]);
-                if (m.emissive.size != 0u) {
-                    const bool s1set = m.emissive_texcoord >= 1u;
-                    if (COUNT) c_texel++;
-                    emissive = emissive * linear_rgb(lin_lut, fetch_texel(a.sc, m.emissive.offset, m.emissive.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
-                }
-                float metallic_chance = m.metallic_factor;
-                float roughness = m.roughness_factor;
-                if (m.metallic_roughness.size != 0u) {
-                    const bool s1set = m.metal_r_texcoord >= 1u;
-                    if (COUNT) c_texel++;
-                    const f3 mr = unpack_rgb(fetch_texel(a.sc, m.metallic_roughness.offset, m.metallic_roughness.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
-                    metallic_chance = mr.z;
-                    roughness *= mr.y;
-                }
-
-                const bool metal = rnd(seed) < metallic_chance;
-                const float f0x = metal ? albedo.x : 0.04f;
-                f3 hemi = rand_sphere(seed); // rand_hemisphere, shader.wgsl:675-681
-                if (dot(hemi, sn) < 0.0f) hemi = hemi * -1.0f;
-                const float mt = roughness * roughness * 0.8f;
-                const f3 mn = normalize(F3(mixf(sn.x, hemi.x, mt), mixf(sn.y, hemi.y, mt), mixf(sn.z, hemi.z, mt)));
-                const float pw = powf(1.0f - dot(mn, neg(dir)), 5.0f); // fresnel_schlick, shader.wgsl:791-793
-                const float fresnel_x = f0x + (1.0f - f0x) * pw;
-                const bool specular = rnd(seed) < fresnel_x;
-
-                lit = lit + emissive * thr;
-                if (!specular || metal) thr = thr * albedo;
-                if (specular || metal) {
-                    f3 nd = dir - mn * (2.0f * dot(mn, dir)); // reflect
-                    if (dot(nd, sn) < 0.0f) nd = normalize(nd - sn * dot(nd, sn)); // project_to_hemisphere
-                    dir = nd;
-                } else {
-                    dir = normalize(sn + rand_sphere(seed)); // sample_lambert, shader.wgsl:781-785
-                }
+            f3 sun_term = F3(0.0f, 0.0f, 0.0f);
+            const int what = shade_segment<COUNT, SUN>(a.sc, lin_lut, a.term_prob, origin, dir, thr, lit, seed, tri, primw & 0x7FFFFFFFu, h.x, sun_term, cnt);
+            if (SUN && what == RT_PATH_SHADOW) {
+                to_shadow = true;
+                o0 = make_float4(origin.x, origin.y, origin.z, dir.x);
+                o1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(pix));
+                o2 = make_float4(sun_term.x, sun_term.y, sun_term.z, overflow ? 1.0f : 0.0f);
+                o3 = make_float4(lit.x, lit.y, lit.z, 0.0f);
+            } else if (what == RT_PATH_BOUNCE) {
                 survive = !a.last_bounce;
                 o0 = make_float4(origin.x, origin.y, origin.z, dir.x);
                 o1 = make_float4(dir.y, dir.z, __uint_as_float(seed), __uint_as_float(pix));
@@ -1483,7 +1515,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         }
     }
     if (COUNT) {
-        const unsigned long long s0 = wave_sum(c_shade), s1 = wave_sum(c_miss), s2 = wave_sum(c_kill), s3 = wave_sum(c_texel);
+        const unsigned long long s0 = wave_sum(cnt.shade), s1 = wave_sum(cnt.miss), s2 = wave_sum(cnt.kill), s3 = wave_sum(cnt.texel);
         if (lane_id() == 0) {
             if (s0) atomicAdd(&a.counters[C_SHADE], s0);
             if (s1) atomicAdd(&a.counters[C_MISS], s1);

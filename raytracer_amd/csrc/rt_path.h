@@ -1,0 +1,520 @@
+// The whole of cs_main (shader.wgsl:886-953) for calls of a few frames, in ONE persistent launch.
+//
+// A host that shows every sample (the reference's frame(), main.rs:356-407: one dispatch per
+// redraw) hands over one to three frames per call.  The staged pipeline of rt_kernels.h then spends
+// most of the call in the tails of its per-bounce launches: a persistent launch ends when its
+// slowest wave does, and one frame has thirteen launches.  Here a lane owns a PATH instead of a
+// ray: it makes the camera ray itself (camera_path, the generate stage's code), walks it through
+// the primitives with the extend stage's lane state machine, and when the ray retires runs the
+// shade stage's code (shade_segment) in place and either ends the path -- its result goes to the
+// path's accumulation slot -- or carries on with the bounced ray.  No queues, no hit records, no
+// launches between bounces; one tail per call.
+//
+// Everything a path computes is the code the staged pipeline runs for it (same functions, same
+// operand order), so its result is bit-identical; paths only finish in another order, which no
+// result depends on (one writer per accumulation slot, frames summed in frame order afterwards).
+//
+// Scenes of up to 128 primitives (one chunk of candidates) and traversal stacks that fit the LDS
+// column; everything else keeps the staged pipeline.
+#pragma once
+
+#include "rt_kernels.h"
+
+#define ST_SHADE 7u   // its ray is traced: the bounce loop's miss / kill / BRDF is next
+
+// four waves per SIMD (128 registers each): a CU's 160 KB of LDS gives each of its four blocks 40 KB
+#ifndef RT_PATH_WAVES
+#define RT_PATH_WAVES 4
+#endif
+#define RT_PATH_MAX_FRAMES 3u     // frames per call up to which a call runs this way
+#ifndef RT_PATH_LDS_LEVELS
+#define RT_PATH_LDS_LEVELS 23u   // the reference's stack depth (shader.wgsl:303)
+#endif
+// Lanes that must be waiting (with a traced ray, or without a path) before the wave runs a path
+// round for them while others still have traversal work: this many, or one in RT_PATH_HEAVY_DIV of
+// the lanes that are in play, whichever is fewer
+#ifndef RT_PATH_HEAVY_LANES
+#define RT_PATH_HEAVY_LANES 24
+#endif
+#ifndef RT_PATH_HEAVY_DIV
+#define RT_PATH_HEAVY_DIV 3u
+#endif
+// a wave with at most this many lanes at traversal work stops voting: every lane steps every round
+#ifndef RT_PATH_UNIFIED_LANES
+#define RT_PATH_UNIFIED_LANES 16u
+#endif
+#ifndef RT_PATH_RUN_SLOTS
+#define RT_PATH_RUN_SLOTS 64u
+#endif
+
+struct PathArgs {
+    SceneDev  sc;
+    GenArgs   gen;            // camera constants, frames of the call, slot -> pixel mapping (out / count_out unused)
+    uint32_t* cursor;         // next camera path to hand out; must start at zero
+    uint32_t  n_slots;        // tiles * 64 * frames
+    uint32_t  max_bounces;
+    uint32_t  stack_depth;
+    float     term_prob;
+    float4*   partial;        // one accumulation slot per (frame slot, pixel): written once, by the path's end
+    float4*   accum;          // direct != 0 (a call of ONE frame): screen itself, shader.wgsl:947-951
+    uint32_t  direct;
+    uint32_t  overwrite;      // reject_hist
+    uint32_t  no_cull;        // a handful of primitives: every primitive is a candidate
+    uint32_t  tap;            // record primary hits and final seeds (frame slot 0)
+    uint32_t  n_pixels;
+    uint32_t  nan_overflow;
+    int32_t*  tap_tri;
+    int32_t*  tap_prim;
+    float*    tap_t;
+    uint32_t* tap_seed;
+    unsigned long long* counters;
+    unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped; // see ExtArgs
+#ifdef RT_PROBE
+    unsigned long long* probe; // diagnostic build: eight words per wave, see the end of k_path
+#endif
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
+    __shared__ uint32_t lds_stack[4 * RT_PATH_LDS_LEVELS * RT_WAVE];
+    __shared__ float lds_ray[6 * 256];   // world-space origin and direction of the lane's current ray
+    __shared__ float lds_path[6 * 256];  // throughput and lighting of the lane's path
+    __shared__ float lin_lut[256];
+    lin_lut[threadIdx.x & 255u] = powf((float)(threadIdx.x & 255u) / 255.0f, 2.2f); // as k_shade
+    __syncthreads();
+    float* const ray = lds_ray + threadIdx.x;
+    float* const pth = lds_path + threadIdx.x;
+    const uint32_t lane = lane_id();
+    uint32_t* const stack = lds_stack + (threadIdx.x >> 6) * (RT_PATH_LDS_LEVELS * RT_WAVE) + lane;
+    const uint32_t n = a.n_slots;
+    const uint32_t depth = min(a.stack_depth, RT_PATH_LDS_LEVELS);
+    const SceneDev& sc = a.sc;
+    const void* const nodes = sc.nodes;
+    const void* const tris = sc.tris;
+    unsigned long long c_rays = 0, c_prims = 0, c_inner = 0, c_leaf = 0, c_tri = 0, c_alpha = 0, c_texel = 0, c_over = 0, c_paths = 0;
+    unsigned long long r_prim = 0, r_inner = 0, r_leaf = 0, r_batch = 0; // wave-uniform
+    ShadeCounts cnt;
+
+    uint32_t run_next = 0, run_end = 0, cursor_seen = 0;
+    bool drained = false;
+#ifdef RT_PROBE
+    const unsigned long long pr_start = wall_clock64();
+    unsigned long long pr_drain = 0, pr_lanes = 0, pr_lanes_tail = 0;
+    uint32_t pr_trav = 0, pr_shade = 0, pr_scan = 0, pr_refill = 0, pr_tail = 0, pr_shade_lanes = 0, pr_scan_lanes = 0;
+    unsigned long long pr_heavy_ticks = 0;
+    uint32_t pr_unified = 0;
+#endif
+
+    // per-lane: the path
+    uint32_t st = ST_DONE;
+    uint32_t pix = 0, bounce = 0, seed = 0;
+    // per-lane: its current ray's closest hit so far (what the staged pipeline keeps in the hit record)
+    float closest_t = 0.0f;
+    int32_t hit_i = -1;
+    uint32_t hit_prim = 0;
+    // per-lane: the walk
+    uint32_t mask[4] = {0, 0, 0, 0};
+    uint32_t pm = 0;
+    uint32_t cur_first = 0, cur_count = 0, sp = 0;
+    f3 lo = F3(0, 0, 0), ld = F3(0, 0, 1), lidir = ld;
+    float scale = 1.0f, best_t = 0.0f;
+    int32_t best_i = -1;
+
+    // the ray is traced
+    auto retire = [&]() {
+        if (pm & RT_PM_OVERFLOW) hit_prim |= 0x80000000u;
+        if (a.tap && bounce == 0u && pix < a.n_pixels) {
+            a.tap_tri[pix] = hit_i;
+            a.tap_prim[pix] = hit_i >= 0 ? (int32_t)(hit_prim & 0x7FFFFFFFu) : -1;
+            a.tap_t[pix] = closest_t;
+        }
+        st = ST_SHADE;
+    };
+    auto advance = [&]() {
+        if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) st = ST_PRIM;
+        else retire();
+    };
+    auto finish = [&]() { // shader.wgsl:610-614
+        if (best_i >= 0) {
+            closest_t = best_t / scale;
+            hit_i = best_i;
+            hit_prim = pm & RT_PM_PRIM;
+        }
+        advance();
+    };
+    auto enter = [&](uint32_t first, uint32_t count) {
+        cur_first = first;
+        cur_count = count;
+        st = count > 0u ? ST_LEAF : ST_INNER;
+        if (COUNT && count > 0u) c_leaf++;
+    };
+    auto enter_desc = [&](uint32_t e) {
+        uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
+        if (e & RT_STACK_RELOAD) {
+            const float4 q = rec16(nodes, (e & 0x7FFFFFFFu) * 2u)[1];
+            first = __float_as_uint(q.z);
+            count = __float_as_uint(q.w);
+        }
+        enter(first, count);
+    };
+    auto pop_or_finish = [&]() {
+        if (sp == 0u) finish();
+        else { --sp; enter_desc(stack[sp * RT_WAVE]); }
+    };
+    // a new segment of the lane's path: what the extend stage does when it fetches a ray
+    auto begin_ray = [&](f3 o, f3 d) {
+        ray[0] = o.x; ray[256] = o.y; ray[512] = o.z;
+        ray[768] = d.x; ray[1024] = d.y; ray[1280] = d.z;
+        closest_t = 99999999.0f; // shader.wgsl:600
+        hit_i = -1;
+        hit_prim = 0u;
+        pm = 0;
+        if (COUNT) c_rays++;
+        if (d.x != d.x && d.y != d.y && d.z != d.z) { // a direction of NaNs: see k_extend
+            if (a.nan_overflow != 0u) pm = RT_PM_OVERFLOW;
+            if (COUNT) {
+                c_prims += sc.n_prims;
+                c_inner += a.nan_inner;
+                c_leaf += a.nan_leaf;
+                c_tri += a.nan_tri;
+                c_over += a.nan_dropped;
+            }
+            retire();
+        } else if (a.no_cull) {
+            mask[0] = sc.n_prims >= 32u ? ~0u : (1u << sc.n_prims) - 1u;
+            mask[1] = 0u; mask[2] = 0u; mask[3] = 0u;
+            advance();
+        } else {
+            st = ST_SCAN;
+        }
+    };
+
+    // ---- the three traversal steps (as in k_extend), on records the caller has fetched
+    // an inner node: its two children (shader.wgsl:496-521)
+    auto inner_step = [&](float4 b0, float4 b1, float4 b2, uint2 dsc) {
+        if (COUNT) c_inner++;
+        const float left = hit_aabb6(lo, lidir, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+        const float right = hit_aabb6(lo, lidir, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w);
+        const bool lmiss = (left < -0.5f || left > best_t);
+        const bool rmiss = (right < -0.5f || right > best_t);
+        if (lmiss && rmiss) {
+            pop_or_finish();
+        } else {
+            const bool go_left = rmiss ? true : (lmiss ? false : left < right);
+            if (!lmiss && !rmiss) {
+                if (sp < depth) { stack[sp * RT_WAVE] = go_left ? dsc.y : dsc.x; sp++; }
+                else { pm |= RT_PM_OVERFLOW; if (COUNT) c_over++; } // shader.wgsl:306-313
+            }
+            enter_desc(go_left ? dsc.x : dsc.y);
+        }
+    };
+    // up to two triangles of the lane's leaf (shader.wgsl:458-495)
+    auto leaf_step = [&](rt_float3 a0, rt_float3 a1, rt_float3 a2, rt_float3 b0, rt_float3 b1, rt_float3 b2, bool two) {
+        auto test = [&](rt_float3 q0, rt_float3 q1, rt_float3 q2, uint32_t tri_i) {
+            if (COUNT) c_tri++;
+            float u, v;
+            const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
+            if (t >= 0.0f && t < best_t) {
+                bool accept = true;
+                if (pm >= (1u << RT_PM_MODE_SHIFT)) { // shader.wgsl:464-487
+                    if (COUNT) c_alpha++;
+                    const uint32_t mode = pm >> RT_PM_MODE_SHIFT;
+                    const PrimX& px = sc.primx[pm & RT_PM_PRIM];
+                    const float w0 = (1.0f - u) - v;
+                    const uint32_t set = px.albedo_texcoord > 1u ? 1u : px.albedo_texcoord;
+                    const float2* e = reinterpret_cast<const float2*>(sc.exts + 6 * (size_t)tri_i);
+                    const float2 t0 = e[set], t1 = e[4 + set], t2 = e[8 + set];
+                    float tcx = 0.0f, tcy = 0.0f;
+                    tcx += w0 * t0.x; tcy += w0 * t0.y;
+                    tcx += u * t1.x;  tcy += u * t1.y;
+                    tcx += v * t2.x;  tcy += v * t2.y;
+                    float alpha = 1.0f; // placeholder texture, shader.wgsl:215-226
+                    const uint32_t asize = px.albedo_size;
+                    if (asize != 0u) {
+                        if (COUNT) c_texel++;
+                        alpha = (float)(fetch_texel(sc, px.albedo_offset, asize, tcx, tcy) & 255u) / 255.0f;
+                    }
+                    if (mode == 1u) accept = !(alpha < (float)(px.alpha_settings >> 16) / 65536.0f);
+                    else accept = !(rnd(seed) > alpha); // BLEND draws from the path's random stream
+                }
+                if (accept) { best_i = (int32_t)tri_i; best_t = t; }
+            }
+        };
+        test(a0, a1, a2, cur_first);
+        if (two) test(b0, b1, b2, cur_first + 1u);
+        const uint32_t done = two ? 2u : 1u;
+        cur_first += done;
+        cur_count -= done;
+        if (cur_count == 0u) pop_or_finish();
+    };
+    // the next candidate primitive, in index order
+    auto next_candidate = [&]() -> uint32_t {
+        uint32_t k;
+        if (mask[0]) { k = __builtin_ctz(mask[0]); mask[0] &= mask[0] - 1u; }
+        else if (mask[1]) { k = 32u + __builtin_ctz(mask[1]); mask[1] &= mask[1] - 1u; }
+        else if (mask[2]) { k = 64u + __builtin_ctz(mask[2]); mask[2] &= mask[2] - 1u; }
+        else { k = 96u + __builtin_ctz(mask[3]); mask[3] &= mask[3] - 1u; }
+        return k;
+    };
+    // the ray enters primitive p: m0..m2 = rows of its inverse transform, r0, r1 = its root node
+    auto prim_step = [&](uint32_t p, float4 m0, float4 m1, float4 m2, float4 r0, float4 r1) {
+        const f3 o = F3(ray[0], ray[256], ray[512]), d = F3(ray[768], ray[1024], ray[1280]);
+        const uint32_t settings = __float_as_uint(r1.w);
+        r1.w = __uint_as_float(settings & RT_PRIMX_COUNT_MASK);
+        const float inv[12] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w};
+        // transform_ray + scale factor, shader.wgsl:604-607
+        const f3 td = xform_dir(d, inv);
+        scale = length(td);
+        ld = td / scale;
+        lo = xform_pos(o, inv);
+        lidir = rcp3(ld);
+        pm = (pm & RT_PM_OVERFLOW) | p | (((settings >> RT_PRIMX_MODE_SHIFT) & 3u) << RT_PM_MODE_SHIFT);
+        const bool nested = (settings & RT_PRIMX_NESTED_ROOT) != 0u;
+        if (COUNT) c_prims++;
+        const float troot = hit_aabb_s(lo, lidir, r0, r1);
+        const uint32_t root_first = __float_as_uint(r1.z), root_count = __float_as_uint(r1.w);
+        best_t = closest_t * scale;
+        best_i = -1;
+        sp = 0;
+        if (troot < -0.5f) { // shader.wgsl:448
+            advance();
+        } else if (nested && troot > best_t) { // see k_extend
+            if (COUNT) c_inner++;
+            advance();
+        } else {
+            enter(root_first, root_count);
+        }
+    };
+
+    for (;;) {
+        const uint32_t n_prim = (uint32_t)__popcll(__ballot(st == ST_PRIM));
+        const uint32_t n_inner = (uint32_t)__popcll(__ballot(st == ST_INNER));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(st == ST_LEAF));
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(st == ST_SHADE));
+        const uint32_t n_done = (uint32_t)__popcll(__ballot(st == ST_DONE));
+        const uint32_t n_trav = n_prim + n_inner + n_leaf;
+
+        // ---- path round: the lanes whose ray is traced run the bounce loop's body (shader.wgsl:900-913),
+        // the lanes whose path has ended take a new camera path, and every lane that has a new ray
+        // gets its candidate mask.  Run when enough lanes wait for it, measured against the lanes
+        // that have traversal work: many while the wave is full, few once its paths run out.
+        const uint32_t n_wait = n_shade + (drained ? 0u : n_done);
+        if (n_wait != 0u && (n_trav == 0u || n_wait >= min((uint32_t)RT_PATH_HEAVY_LANES, max(1u, (n_trav + n_wait) / RT_PATH_HEAVY_DIV)))) {
+#ifdef RT_PROBE
+            const unsigned long long pr_t0 = wall_clock64();
+            pr_shade++; pr_shade_lanes += n_shade;
+#endif
+            bool fresh = false;
+            f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+            if (st == ST_SHADE) {
+                f3 origin = F3(ray[0], ray[256], ray[512]), dir = F3(ray[768], ray[1024], ray[1280]);
+                f3 thr = F3(pth[0], pth[256], pth[512]), lit = F3(pth[768], pth[1024], pth[1280]);
+                const bool overflow = (hit_prim >> 31) != 0u;
+                f3 sun_term;
+                int what = shade_segment<COUNT, false>(sc, lin_lut, a.term_prob, origin, dir, thr, lit, seed, hit_i, hit_prim & 0x7FFFFFFFu,
+                                                       closest_t, sun_term, cnt);
+                if (what == RT_PATH_BOUNCE && bounce + 1u == a.max_bounces) what = RT_PATH_END; // loop bound, shader.wgsl:898
+                if (what == RT_PATH_BOUNCE) {
+                    bounce++;
+                    pth[0] = thr.x; pth[256] = thr.y; pth[512] = thr.z;
+                    pth[768] = lit.x; pth[1024] = lit.y; pth[1280] = lit.z;
+                    fresh = true;
+                    o = origin;
+                    d = dir;
+                } else { // shader.wgsl:941-951
+                    if (overflow) lit = F3(1.0f, 1.0f, 0.0f);
+                    if (a.direct) {
+                        float4 acc = make_float4(lit.x, lit.y, lit.z, 1.0f);
+                        if (!a.overwrite) {
+                            const float4 old = a.accum[pix];
+                            acc = make_float4(old.x + lit.x, old.y + lit.y, old.z + lit.z, old.w + 1.0f);
+                        }
+                        a.accum[pix] = acc;
+                    } else {
+                        a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
+                    }
+                    if (a.tap && pix < a.n_pixels) a.tap_seed[pix] = seed;
+                    st = ST_DONE;
+                }
+            }
+            // new camera paths for the lanes without a path (those that just ended theirs included)
+            if (!drained) {
+                const unsigned long long done_m = __ballot(st == ST_DONE);
+                if (done_m != 0ull && run_next == run_end) {
+                    // guided reservation, as in k_extend: ever smaller runs towards the end of the call
+                    const uint32_t left = n > cursor_seen ? n - cursor_seen : 0u;
+                    const uint32_t want = min(RT_PATH_RUN_SLOTS, max(RT_RUN_MIN, left / (RT_RUN_DIV * 4u * gridDim.x)));
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(a.cursor, want);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    cursor_seen = base + want;
+                    if (base >= n) {
+                        drained = true;
+#ifdef RT_PROBE
+                        pr_drain = wall_clock64();
+#endif
+                    } else {
+                        run_next = base;
+                        run_end = min(base + want, n);
+                        if (COUNT) r_batch += (run_end - run_next + 63u) >> 6;
+                    }
+                }
+                if (done_m != 0ull && !drained) {
+#ifdef RT_PROBE
+                    pr_refill++;
+#endif
+                    const uint32_t avail = run_end - run_next;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_m, 0u));
+                    if (st == ST_DONE && rank < avail) {
+                        if (camera_path(a.gen, run_next + rank, o, d, seed, pix)) {
+                            if (COUNT) c_paths++;
+                            bounce = 0u;
+                            pth[0] = 1.0f; pth[256] = 1.0f; pth[512] = 1.0f;    // throughput, shader.wgsl:891
+                            pth[768] = 0.0f; pth[1024] = 0.0f; pth[1280] = 0.0f; // lighting, :892
+                            fresh = true;
+                        }
+                    }
+                    run_next += min(avail, (uint32_t)__popcll(done_m));
+                }
+            }
+            if (fresh) begin_ray(o, d);
+            // candidate masks of the new rays (k_cull's loop: wave-uniform over the primitives)
+            const bool mine = st == ST_SCAN;
+            if (__ballot(mine) != 0ull) {
+#ifdef RT_PROBE
+                pr_scan++; pr_scan_lanes += (uint32_t)__popcll(__ballot(mine));
+#endif
+                f3 oi, idir;
+                world_test_ray(o, d, oi, idir);
+                uint32_t m[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    uint32_t mw = 0;
+#pragma unroll 1
+                    for (uint32_t gg = 0; gg < 4u; gg++) {
+                        const uint32_t g = 4u * w + gg;
+                        if (g >= sc.n_prim_groups) break;
+                        const rt_float8 u = *(rt_cfloat8_p)(sc.gbounds + (size_t)g * 8u);
+                        const float ub[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
+                        if (__ballot(mine && overlaps_world_box(oi, idir, ub)) == 0ull) continue;
+                        const rt_cfloat8_p bp = (rt_cfloat8_p)(sc.wbounds + (size_t)g * 48u);
+                        const rt_float8 lx = bp[0], ly = bp[1], lz = bp[2], hx = bp[3], hy = bp[4], hz = bp[5];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const float b[6] = {lx[k], ly[k], lz[k], hx[k], hy[k], hz[k]};
+                            mw |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (gg * 8u + k);
+                        }
+                    }
+                    const uint32_t first = 32u * w;
+                    const uint32_t have = sc.n_prims > first ? min(sc.n_prims - first, 32u) : 0u;
+                    m[w] = have >= 32u ? mw : (mw & ((1u << have) - 1u));
+                }
+                if (mine) {
+                    mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];
+                    advance();
+                }
+            }
+#ifdef RT_PROBE
+            pr_heavy_ticks += wall_clock64() - pr_t0;
+#endif
+            continue;
+        }
+
+        if (n_trav == 0u) break; // every path has ended and no camera path is left
+#ifdef RT_PROBE
+        pr_trav++; pr_lanes += n_trav;
+        if (drained) { pr_tail++; pr_lanes_tail += n_trav; }
+#endif
+
+        if (n_trav <= RT_PATH_UNIFIED_LANES) {
+            // ---- thin wave (its paths are running out): every lane takes its next step, whatever
+            // its kind.  One set of fetches at the lane's sibling pair, triangles or primitive
+            // record, one wait, then the three step bodies under their masks.  The plurality vote
+            // below serves one kind per round; with a dozen lanes left that leaves most of them
+            // waiting, and the end of the launch is the time its last rays need.
+#ifdef RT_PROBE
+            pr_unified++;
+#endif
+            const bool is_inner = st == ST_INNER, is_leaf = st == ST_LEAF, is_prim = st == ST_PRIM;
+            const bool two = is_leaf && cur_count > 1u;
+            if (COUNT) { if (__ballot(is_inner)) r_inner++; if (__ballot(is_leaf)) r_leaf += __ballot(two) ? 2u : 1u; if (__ballot(is_prim)) r_prim++; }
+            uint32_t p = 0;
+            const float4* base = rec16(sc.pairs, cur_first * 2u);
+            if (is_leaf) base = rec16(tris, cur_first * 3u);
+            if (is_prim) {
+                p = next_candidate();
+                base = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
+            }
+            float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
+            if (is_inner || is_leaf || is_prim) { q0 = base[0]; q1 = base[1]; q2 = base[2]; }
+            if (is_inner) { const uint2 dd = *reinterpret_cast<const uint2*>(base + 3); q3.x = __uint_as_float(dd.x); q3.y = __uint_as_float(dd.y); }
+            if (is_prim || two) { q3 = base[3]; q4 = base[4]; }
+            if (two) q5 = base[5];
+            if (is_inner) {
+                inner_step(q0, q1, q2, make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y)));
+            } else if (is_leaf) {
+                rt_float3 a0 = {q0.x, q0.y, q0.z}, a1 = {q1.x, q1.y, q1.z}, a2 = {q2.x, q2.y, q2.z};
+                rt_float3 b0 = {q3.x, q3.y, q3.z}, b1 = {q4.x, q4.y, q4.z}, b2 = {q5.x, q5.y, q5.z};
+                leaf_step(a0, a1, a2, b0, b1, b2, two);
+            } else if (is_prim) {
+                prim_step(p, q0, q1, q2, q3, q4);
+            }
+        } else if (n_inner >= n_prim && n_inner >= n_leaf) {
+#pragma unroll 1
+            for (int burst = 0; burst < RT_INNER_BURST; burst++) {
+                if (COUNT) r_inner++;
+                if (st == ST_INNER) {
+                    const float4* np = rec16(sc.pairs, cur_first * 2u);
+                    const float4 b0 = np[0], b1 = np[1], b2 = np[2];
+                    const uint2 dsc = *reinterpret_cast<const uint2*>(np + 3);
+                    inner_step(b0, b1, b2, dsc);
+                }
+                if (__ballot(st == ST_INNER) == 0ull) break;
+            }
+        } else if (n_leaf >= n_prim) {
+            const bool two = st == ST_LEAF && cur_count > 1u;
+            if (COUNT) r_leaf += __ballot(two) ? 2u : 1u;
+            if (st == ST_LEAF) {
+                const float4* tp = rec16(tris, cur_first * 3u);
+                const rt_float3 a0 = ld12(tp), a1 = ld12(tp + 1), a2 = ld12(tp + 2);
+                rt_float3 b0 = a0, b1 = a1, b2 = a2;
+                if (two) { b0 = ld12(tp + 3); b1 = ld12(tp + 4); b2 = ld12(tp + 5); }
+                leaf_step(a0, a1, a2, b0, b1, b2, two);
+            }
+        } else {
+            if (COUNT) r_prim++;
+            if (st == ST_PRIM) {
+                const uint32_t p = next_candidate();
+                const float4* pp = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
+                const float4 m0 = pp[0], m1 = pp[1], m2 = pp[2], r0 = pp[3], r1 = pp[4];
+                prim_step(p, m0, m1, m2, r0, r1);
+            }
+        }
+    }
+#ifdef RT_PROBE
+    if (a.probe && lane == 0) {
+        unsigned long long* r = a.probe + 8ull * ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6));
+        r[0] = pr_start; r[1] = pr_drain; r[2] = wall_clock64();
+        r[3] = pr_trav | ((unsigned long long)pr_tail << 32);                  // traversal rounds: all, after the drain
+        r[4] = pr_lanes | ((unsigned long long)pr_unified << 40);                                                       // lanes with traversal work, summed over those rounds
+        r[5] = pr_lanes_tail | (pr_heavy_ticks << 32);                         // ... after the drain; ticks spent in path rounds
+        r[6] = pr_shade | ((unsigned long long)pr_shade_lanes << 32);
+        r[7] = pr_scan | ((unsigned long long)pr_scan_lanes << 32) | ((unsigned long long)pr_refill << 48);
+    }
+#endif
+    if (COUNT) {
+        const unsigned long long v[13] = {c_rays, c_prims, c_inner, c_leaf, c_tri, c_alpha, c_texel + cnt.texel, c_over, c_paths, cnt.shade, cnt.miss, cnt.kill, 0};
+        const int idx[12] = {C_RAYS, C_PRIMS, C_INNER, C_LEAF, C_TRI, C_ALPHA, C_TEXEL, C_OVERFLOW, C_PATHS, C_SHADE, C_MISS, C_KILL};
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned long long sum = wave_sum(v[k]);
+            if (lane == 0 && sum) atomicAdd(&a.counters[idx[k]], sum);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters[C_ROUNDS_PRIM], r_prim);
+            atomicAdd(&a.counters[C_ROUNDS_INNER], r_inner);
+            atomicAdd(&a.counters[C_ROUNDS_LEAF], r_leaf);
+            atomicAdd(&a.counters[C_BATCHES], r_batch);
+        }
+    }
+}

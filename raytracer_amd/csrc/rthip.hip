@@ -3,6 +3,7 @@
 
 #include "../../include/rthip.h"
 #include "rt_kernels.h"
+#include "rt_path.h"
 
 #include <algorithm>
 #include <cmath>
@@ -248,6 +249,33 @@ uint32_t frames_in_flight_limit(const rthip_ctx* c) {
     return want;
 }
 
+// `screen` for the current resolution: the caller's bound buffer, or a library-owned one that a
+// change of resolution replaces by a zeroed one of the new size (update_resolution, main.rs:79-94).
+int ensure_accum(rthip_ctx* c) {
+    const uint64_t n = c->n_pixels;
+    if (c->accum_is_bound) {
+        if (c->accum_own) { // not in use while a caller's buffer is bound
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            free_dev_t(c->accum_own);
+            c->accum_own_pixels = 0;
+        }
+        return RTHIP_OK;
+    }
+    if (c->accum_own && c->accum_own_pixels != n) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_dev_t(c->accum_own);
+        c->accum_own_pixels = 0;
+        c->accum = nullptr;
+    }
+    if (!c->accum_own) {
+        HIP_TRY(c, hipMalloc((void**)&c->accum_own, sizeof(float4) * n));
+        c->accum_own_pixels = n;
+        HIP_TRY(c, hipMemsetAsync(c->accum_own, 0, sizeof(float4) * n, c->stream));
+    }
+    c->accum = c->accum_own;
+    return RTHIP_OK;
+}
+
 // Queue slots are handed out per 8x8 pixel tile, so the work buffers are keyed on the resolution
 // itself: two resolutions of equal pixel count can differ in tiles (1000x500 has 7875, 2000x250 has
 // 8000).  The library-owned accumulator is keyed on the pixel count and survives a re-allocation
@@ -273,26 +301,7 @@ int ensure_frame_buffers(rthip_ctx* c, uint32_t frames) {
         c->buf_res_x = c->res_x;
         c->buf_res_y = c->res_y;
     }
-    if (c->accum_is_bound) {
-        if (c->accum_own) { // not in use while a caller's buffer is bound
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            free_dev_t(c->accum_own);
-            c->accum_own_pixels = 0;
-        }
-    } else {
-        if (c->accum_own && c->accum_own_pixels != n) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            free_dev_t(c->accum_own);
-            c->accum_own_pixels = 0;
-        }
-        if (!c->accum_own) {
-            HIP_TRY(c, hipMalloc((void**)&c->accum_own, sizeof(float4) * n));
-            c->accum_own_pixels = n;
-            HIP_TRY(c, hipMemsetAsync(c->accum_own, 0, sizeof(float4) * n, c->stream));
-        }
-        c->accum = c->accum_own;
-    }
-    return RTHIP_OK;
+    return ensure_accum(c);
 }
 
 hipEvent_t get_event(rthip_ctx* c) {
@@ -1006,6 +1015,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     // tiles, which is worth 14 % of their throughput.  RTHIP_SPREAD (0, 2, 4) overrides for experiments.
     int spread_env = -1;
     if (const char* e = std::getenv("RTHIP_SPREAD")) spread_env = std::atoi(e);
+    int path_blocks_env = 0;
+    if (const char* e = std::getenv("RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
+    const bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
 
     PathQueue q[2];
     for (int k = 0; k < 2; k++) {
@@ -1075,6 +1087,76 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const bool short_call = nf <= 2u && ga.n_tiles >= 64u;
         ga.spread_shift = short_call ? 2u : 0u;
         if (spread_env == 0 || ((spread_env == 2 || spread_env == 4) && ga.n_tiles >= 64u)) ga.spread_shift = (uint32_t)spread_env;
+        // A call of a few frames runs as ONE persistent launch in which a lane owns a whole path
+        // (rt_path.h): the staged pipeline below would spend most of such a call in the tails of its
+        // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk and
+        // stacks that fit the LDS column only.
+        const bool fused = !staged_only && nf <= RT_PATH_MAX_FRAMES && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun;
+        if (fused) {
+            PathArgs pa{};
+            pa.sc = c->sc;
+            pa.gen = ga;
+            pa.gen.spread_shift = (ga.n_tiles >= 64u && spread_env != 0) ? (spread_env == 4 ? 4u : 2u) : 0u;
+            pa.gen.counters = nullptr;
+            pa.cursor = c->ctrl + 64;
+            pa.n_slots = (uint32_t)slots;
+            pa.max_bounces = P.max_bounces;
+            pa.stack_depth = P.stack_depth;
+            pa.term_prob = P.term_prob;
+            pa.partial = c->partial;
+            pa.accum = c->accum;
+            pa.direct = nf == 1u ? 1u : 0u;
+            pa.overwrite = overwrite ? 1u : 0u;
+            pa.no_cull = cull ? 0u : 1u;
+            pa.tap = tap_group ? 1u : 0u;
+            pa.n_pixels = (uint32_t)c->n_pixels;
+            pa.tap_tri = c->tap_tri;
+            pa.tap_prim = c->tap_prim;
+            pa.tap_t = c->tap_t;
+            pa.tap_seed = c->tap_seed;
+            pa.counters = c->d_counters;
+            pa.nan_inner = nanw.inner;
+            pa.nan_leaf = nanw.leaf;
+            pa.nan_tri = nanw.tri;
+            pa.nan_dropped = nanw.dropped;
+            pa.nan_overflow = nanw.dropped ? 1u : 0u;
+            int pblocks = count ? occupancy_blocks(k_path<true>, 256) : occupancy_blocks(k_path<false>, 256);
+            if (path_blocks_env > 0) pblocks = std::min(pblocks, path_blocks_env);
+            const uint32_t pgrid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * pblocks, (slots + 255) / 256);
+#ifdef RT_PROBE
+            // diagnostic build only (tools/path_probe.py): per-wave records of this launch appended to $RTHIP_PROBE_FILE
+            static unsigned long long* path_probe_buf = nullptr;
+            if (!path_probe_buf) (void)hipMalloc((void**)&path_probe_buf, sizeof(unsigned long long) * 8 * 4 * 65536);
+            pa.probe = std::getenv("RTHIP_PROBE_FILE") ? path_probe_buf : nullptr;
+#endif
+            {
+                StageTimer t(c, timing, RTHIP_STAGE_PATH);
+                if (count) hipLaunchKernelGGL(k_path<true>, dim3(pgrid), dim3(256), 0, c->stream, pa);
+                else hipLaunchKernelGGL(k_path<false>, dim3(pgrid), dim3(256), 0, c->stream, pa);
+            }
+#ifdef RT_PROBE
+            if (pa.probe) {
+                std::vector<unsigned long long> h((size_t)pgrid * 32);
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipMemcpy(h.data(), path_probe_buf, h.size() * 8, hipMemcpyDeviceToHost);
+                if (FILE* f = std::fopen(std::getenv("RTHIP_PROBE_FILE"), "ab")) {
+                    const unsigned long long hdr[2] = {1000, (unsigned long long)pgrid * 4};
+                    std::fwrite(hdr, 8, 2, f);
+                    std::fwrite(h.data(), 8, h.size(), f);
+                    std::fclose(f);
+                }
+            }
+#endif
+            if (!pa.direct) {
+                StageTimer t(c, timing, RTHIP_STAGE_ACCUMULATE);
+                const uint32_t acc_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (c->n_pixels + 255) / 256);
+                hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
+                                   (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
+            }
+            c->reject_hist = 0; // main.rs:403
+            if (tap_group) c->taps_valid = true;
+            continue;
+        }
         {
             StageTimer t(c, timing, RTHIP_STAGE_GENERATE);
             hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(256), 0, c->stream, ga);
@@ -1465,8 +1547,11 @@ int rthip_accum_device_ptr(rthip_ctx* c, void** device_ptr, uint64_t* n_pixels) 
 int rthip_read_accum(rthip_ctx* c, float* rgba, uint64_t n_pixels) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!rgba) return fail(c, RTHIP_ERR_INVALID, "read_accum: null output");
-    if (!c->accum || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "read_accum: %llu pixels requested, accumulator has %llu", (unsigned long long)n_pixels, (unsigned long long)(c->accum ? c->n_pixels : 0));
+    if (!c->have_uniforms || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "read_accum: %llu pixels requested, accumulator has %llu", (unsigned long long)n_pixels, (unsigned long long)(c->have_uniforms ? c->n_pixels : 0));
     DeviceGuard g(c->device);
+    // a change of resolution that no render has followed yet: the accumulator of the new size (zeroed)
+    int rc = ensure_accum(c);
+    if (rc != RTHIP_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(rgba, c->accum, sizeof(float4) * n_pixels, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTHIP_OK;
@@ -1537,8 +1622,12 @@ int rthip_read_tris_device_layout(rthip_ctx* c, void* out, uint64_t n_tris) {
 int rthip_resolve(rthip_ctx* c, uint8_t* rgba8, uint64_t n_pixels, int apply_srgb_oetf) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!rgba8) return fail(c, RTHIP_ERR_INVALID, "resolve: null output");
-    if (!c->accum || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "resolve: size mismatch");
+    if (!c->have_uniforms || n_pixels != c->n_pixels) return fail(c, RTHIP_ERR_INVALID, "resolve: size mismatch");
     DeviceGuard g(c->device);
+    {
+        int rc = ensure_accum(c);
+        if (rc != RTHIP_OK) return rc;
+    }
     if (c->resolve_cap < n_pixels) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         free_dev_t(c->resolve_out);

@@ -14,9 +14,9 @@ from . import layouts as L
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "lib", "librthip.so")
 
-FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING = 1, 2, 4
+FLAG_COUNTERS, FLAG_TAPS, FLAG_TIMING, FLAG_STAGED = 1, 2, 4, 8
 NOALLOC_MAX_RAYS = 1 << 18
-STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "shadow", "cull")
+STAGES = ("generate", "extend", "shade", "resolve", "accumulate", "shadow", "cull", "path")
 
 EXPORTS = (
     "rthip_device_count", "rthip_create", "rthip_destroy", "rthip_last_error", "rthip_set_stream",

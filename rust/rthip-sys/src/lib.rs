@@ -61,8 +61,8 @@ pub struct rthip_counters {
 }
 
 /// Mirrors `rthip_timing`: summed kernel time and launch count per stage
-/// (generate, extend, shade, resolve, accumulate, shadow, cull).
-pub const RTHIP_NUM_STAGES: usize = 7;
+/// (generate, extend, shade, resolve, accumulate, shadow, cull, path).
+pub const RTHIP_NUM_STAGES: usize = 8;
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct rthip_timing {
@@ -73,6 +73,7 @@ pub struct rthip_timing {
 pub const RTHIP_FLAG_COUNTERS: u32 = 1;
 pub const RTHIP_FLAG_TAPS: u32 = 2;
 pub const RTHIP_FLAG_TIMING: u32 = 4;
+pub const RTHIP_FLAG_STAGED: u32 = 8;
 
 extern "C" {
     pub fn rthip_device_count() -> c_int;

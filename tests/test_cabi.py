@@ -82,10 +82,92 @@ def test_product_does_not_import_the_oracle():
                 assert "rt_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
 
 
-def test_rust_ffi_crate_declares_every_c_entry_point():
-    """rust/rthip-sys cannot be compiled here (no cargo); at least its extern blocks must name
-    exactly the functions the two headers declare, so that it does not drift from the ABI."""
+# ---- rust/rthip-sys against the headers: names, arity, and every parameter and return type ---------
+
+C_SCALARS = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "uint8_t": "u8", "float": "f32",
+             "double": "f64", "char": "c_char", "void": "c_void", "size_t": "usize"}
+
+
+def c_type_to_rust(ctype):
+    """'const rthip_scene_desc*' -> '*const rthip_scene_desc'; 'uint32_t' -> 'u32'; 'void' -> ''."""
+    t = ctype.strip()
+    stars = t.count("*")
+    t = t.replace("*", " ")
+    words = t.split()
+    const = "const" in words
+    base = [w for w in words if w not in ("const", "struct")]
+    assert len(base) == 1, ctype
+    name = C_SCALARS.get(base[0], base[0])
+    if stars == 0:
+        return "" if base[0] == "void" else name
+    out = name
+    for level in range(stars):
+        # only the innermost pointee can be const in these headers (const T*, const T**: not used)
+        out = ("*const " if (const and level == 0) else "*mut ") + out
+    return out
+
+
+def c_prototypes(header, prefix):
+    """{name: (return type, [parameter types])} of a header, in the Rust spelling."""
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    protos = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(%s_\w+)\s*\(([^)]*)\)\s*;" % prefix, text):
+        plist = []
+        params = " ".join(params.split())
+        if params and params != "void":
+            for prm in params.split(","):
+                m = re.match(r"(.*?)(\w+)$", prm.strip())      # the last word is the parameter's name
+                plist.append(c_type_to_rust(m.group(1)))
+        protos[name] = (c_type_to_rust(ret), plist)
+    return protos
+
+
+def rust_prototypes(src):
+    protos = {}
+    for name, params, ret in re.findall(r"pub fn (rthip_\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;{]+))?;", src):
+        plist = []
+        for prm in " ".join(params.split()).split(","):
+            if prm.strip():
+                plist.append(" ".join(prm.split(":", 1)[1].split()))
+        protos[name] = (" ".join((ret or "").split()), plist)
+    return protos
+
+
+def test_rust_ffi_crate_matches_the_headers_signature_by_signature():
+    """rust/rthip-sys cannot be compiled here (no cargo), so its extern blocks are checked as text:
+    the same functions as the two headers, each with the same number of parameters, the same
+    parameter types in the same order, and the same return type."""
     src = open(os.path.join(ROOT, "rust", "rthip-sys", "src", "lib.rs")).read()
-    rust = sorted(set(re.findall(r"pub fn (rthip_\w+)\s*\(", src)))
-    want = sorted(set(declared("rthip.h", "rthip")) | set(declared("rthip_group.h", "rthip_group")))
-    assert rust == want, (sorted(set(want) - set(rust)), sorted(set(rust) - set(want)))
+    rust = rust_prototypes(src)
+    want = dict(c_prototypes("rthip.h", "rthip"))
+    want.update(c_prototypes("rthip_group.h", "rthip_group"))
+    assert sorted(rust) == sorted(want), (sorted(set(want) - set(rust)), sorted(set(rust) - set(want)))
+    assert len(want) >= 40
+    for name in sorted(want):
+        assert rust[name] == want[name], (name, rust[name], want[name])
+
+
+def test_rust_ffi_crate_mirrors_the_structs_and_constants():
+    """Field order and types of the #[repr(C)] mirrors, the stage count and the flag values."""
+    src = open(os.path.join(ROOT, "rust", "rthip-sys", "src", "lib.rs")).read()
+    hdr = open(os.path.join(ROOT, "include", "rthip.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for struct in ("rthip_scene_desc", "rthip_render_params", "rthip_counters"):
+        body = re.search(r"typedef struct \{([^{}]*)\} %s;" % struct, hdr_nc).group(1)
+        c_fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(.*?)(\w+(?:\s*,\s*\w+)*)$", decl)
+            for fname in m.group(2).split(","):
+                c_fields.append((fname.strip(), c_type_to_rust(m.group(1))))
+        rbody = re.search(r"pub struct %s \{([^{}]*)\}" % struct, src).group(1)
+        r_fields = [(n, " ".join(t.split())) for n, t in re.findall(r"pub (\w+):\s*([^,\n]+),", rbody)]
+        assert r_fields == c_fields, (struct, r_fields, c_fields)
+    for const in ("RTHIP_NUM_STAGES", "RTHIP_FLAG_COUNTERS", "RTHIP_FLAG_TAPS", "RTHIP_FLAG_TIMING", "RTHIP_FLAG_STAGED"):
+        c_val = int(re.search(r"#define %s\s+(\d+)" % const, hdr).group(1))
+        r_val = int(re.search(r"pub const %s: \w+ = (\d+);" % const, src).group(1))
+        assert c_val == r_val, const

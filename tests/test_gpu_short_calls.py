@@ -1,0 +1,196 @@
+"""Calls of one to three frames run as one persistent launch in which a lane owns a whole path
+(k_path); longer calls, and calls with RTHIP_FLAG_STAGED, go through the staged pipeline (generate /
+cull / extend / shade per bounce).  Both run the same code per path, so everything they produce must
+be equal bit for bit -- accumulators, primary-hit taps, final RNG states, traversal counters -- and
+the short path must stand against the oracle on its own.
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import device, procedural
+from util import oracle_params, oracle_scene, psnr, tonemapped
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {
+    "box": (procedural.box_scene, dict(env_size=(64, 32)), (67, 41)),
+    "materials": (procedural.material_test_scene, dict(tex=64, env_size=(128, 64)), (160, 96)),   # MASK + BLEND, two UV sets, instancing
+    "terrain": (procedural.terrain_scene, dict(env_size=(128, 64)), (128, 72)),
+    "atrium": (procedural.atrium_scene, dict(detail=0.25, tex=64), (320, 180)),                   # 103 primitives: candidate masks
+}
+EXACT = ("rays", "prims_visited", "inner_steps", "leaf_steps", "tri_tests", "alpha_tests", "texel_fetches", "shade_calls",
+         "misses", "kills", "stack_overflows", "paths")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = device.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    out = {}
+    for name, (fn, kw, res) in SCENES.items():
+        s = fn(**kw)
+        out[name] = (s, s.arrays(), res)
+    return out
+
+
+def render(ctx, scene, res, calls, flags=0, **kw):
+    """calls: list of (first_frame, n_frames).  Returns accumulator, taps of the first call, counters."""
+    p = device.default_params(**kw)
+    p.flags = flags | device.FLAG_COUNTERS
+    ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=calls[0][0], reject_hist=1))
+    ctx.reset_counters()
+    taps = None
+    for i, (first, n) in enumerate(calls):
+        if i == 0:
+            p.flags |= device.FLAG_TAPS
+        else:
+            p.flags &= ~device.FLAG_TAPS
+        ctx.render(first, n, 1, p)
+        if i == 0:
+            taps = ctx.read_taps()
+    return ctx.read_accum(), taps, ctx.counters()
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name):
+    s, a, res = scenes[name]
+    ctx.upload_scene(a)
+    kw = dict(max_bounces=5)
+    one_by_one = [(1, 1), (2, 1), (3, 1)]
+    ref_acc, ref_taps, ref_cnt = render(ctx, s, res, one_by_one, flags=device.FLAG_STAGED, **kw)
+    variants = {
+        "short, one frame per call": (one_by_one, 0),
+        "short, three frames in one call": ([(1, 3)], 0),
+        "short, two frames then one": ([(1, 2), (3, 1)], 0),
+        "staged, three frames in one call": ([(1, 3)], device.FLAG_STAGED),
+    }
+    for label, (calls, flags) in variants.items():
+        acc, taps, cnt = render(ctx, s, res, calls, flags=flags, **kw)
+        assert np.array_equal(acc, ref_acc), label
+        for k in ("tri", "prim", "t", "seed"):
+            assert np.array_equal(taps[k], ref_taps[k]), (label, k)
+        for k in EXACT:
+            assert cnt[k] == ref_cnt[k], (label, k, cnt[k], ref_cnt[k])
+    assert np.all(ref_acc[..., 3] == 3.0)
+
+
+def test_short_path_is_the_one_that_runs(ctx, scenes):
+    """Timing records which launches a call made: one to three frames = one k_path launch and no
+    stage launch; four frames = the staged pipeline."""
+    s, a, res = scenes["materials"]
+    ctx.upload_scene(a)
+    ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+    p = device.default_params(flags=device.FLAG_TIMING)
+    for n, want_path in ((1, 1), (2, 1), (3, 1), (4, 0)):
+        ctx.reset_timing()
+        ctx.render(1, n, 1, p)
+        t = ctx.timing()
+        assert t["path"]["launches"] == want_path, (n, t)
+        assert (t["extend"]["launches"] == 0) == (want_path == 1), (n, t)
+    # a stack deeper than the short path's LDS column, and the sun option, keep the staged pipeline
+    for kw in (dict(stack_depth=40), dict(enable_sun=1)):
+        ctx.reset_timing()
+        ctx.render(1, 1, 1, device.default_params(flags=device.FLAG_TIMING, **kw))
+        assert ctx.timing()["path"]["launches"] == 0, kw
+
+
+@pytest.mark.parametrize("name", ["materials", "atrium"])
+def test_short_path_matches_oracle(ctx, scenes, name):
+    s, a, res = scenes[name]
+    ctx.upload_scene(a)
+    acc, taps, cnt = render(ctx, s, res, [(5, 1)], max_bounces=8)
+    p = device.default_params(max_bounces=8)
+    u = s.frame_uniforms(res, frame=5, reject_hist=1)
+    ref = orc.render(oracle_scene(a), u, oracle_params(p), 5, 1, 1, taps=True, n_threads=8)
+    n = res[0] * res[1]
+    assert float((taps["tri"] == ref["tri"]).mean()) >= 0.9999
+    same = taps["tri"] == ref["tri"]
+    assert np.array_equal(taps["prim"][same], ref["prim"][same])
+    np.testing.assert_allclose(taps["t"][same], ref["t"][same], rtol=1e-5, atol=1e-6)   # the camera ray's sin / cos come from another library
+    ok = taps["seed"] == ref["seed"]
+    assert float(ok.mean()) >= 0.998
+    assert np.array_equal(acc[..., 3], ref["accum"][..., 3])
+    np.testing.assert_allclose(acc[ok], ref["accum"][ok], rtol=2e-3, atol=2e-4)
+    for k in ("rays", "shade_calls", "misses", "kills", "inner_steps", "tri_tests"):
+        assert abs(cnt[k] - ref["counters"][k]) <= max(4, 3e-3 * ref["counters"][k]), k
+    assert cnt["paths"] == n
+
+
+def test_short_path_converges_to_the_oracle_image(ctx, scenes):
+    """48 calls of one frame each, the reference's call pattern (main.rs:356-407), against the oracle."""
+    s, a, _ = scenes["materials"]
+    res = (96, 64)
+    ctx.upload_scene(a)
+    acc, _, _ = render(ctx, s, res, [(f, 1) for f in range(1, 49)])
+    ref = orc.render(oracle_scene(a), s.frame_uniforms(res, frame=1, reject_hist=1), oracle_params(device.default_params()), 1, 48, 1, n_threads=8)
+    assert np.all(acc[..., 3] == 48.0)
+    assert psnr(tonemapped(acc), tonemapped(ref["accum"])) >= 45.0
+
+
+@pytest.mark.parametrize("depth", [2, 5, 23])
+def test_short_path_drops_pushes_like_the_staged_pipeline(ctx, scenes, depth):
+    s, a, res = scenes["terrain"]
+    ctx.upload_scene(a)
+    acc0, taps0, cnt0 = render(ctx, s, res, [(1, 2)], flags=device.FLAG_STAGED, stack_depth=depth)
+    acc1, taps1, cnt1 = render(ctx, s, res, [(1, 2)], stack_depth=depth)
+    assert np.array_equal(acc0, acc1)
+    assert np.array_equal(taps0["seed"], taps1["seed"]) and np.array_equal(taps0["tri"], taps1["tri"])
+    for k in EXACT:
+        assert cnt0[k] == cnt1[k], k
+    if depth == 2:
+        assert cnt1["stack_overflows"] > 0
+        yellow = (acc1[..., 0] == acc1[..., 1]) & (acc1[..., 2] == 0.0) & (acc1[..., 0] > 0)
+        assert yellow.any()
+
+
+def test_short_path_nan_directions(ctx, scenes):
+    """Every camera ray with a NaN direction (NaN focus distance): the precomputed walk, as in the staged pipeline."""
+    s, a, _ = scenes["materials"]
+    res = (16, 8)
+    u = np.ascontiguousarray(s.frame_uniforms(res, frame=1, reject_hist=1)).view(np.uint8).reshape(-1).copy()
+    u[540:544] = np.array([np.nan], np.float32).view(np.uint8)
+    ctx.upload_scene(a)
+    out = []
+    for flags in (device.FLAG_STAGED, 0):
+        p = device.default_params(max_bounces=2, flags=flags | device.FLAG_TAPS | device.FLAG_COUNTERS)
+        ctx.set_frame_uniforms(u)
+        ctx.reset_counters()
+        ctx.render(1, 1, 1, p)
+        out.append((ctx.read_accum(), ctx.read_taps(), ctx.counters()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.all(out[1][1]["tri"] == -1)
+    for k in EXACT:
+        assert out[0][2][k] == out[1][2][k], k
+
+
+def test_short_path_into_a_bound_accumulator_and_after_resize(ctx, scenes):
+    """The one-frame form adds into `screen` itself: the caller's buffer when one is bound, and the
+    new buffer after a change of resolution."""
+    import torch
+    s, a, _ = scenes["box"]
+    ctx.upload_scene(a)
+    res = (40, 24)
+    t = torch.full((res[0] * res[1] * 4,), 7.0, dtype=torch.float32, device="cuda:0")
+    ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))   # the resolution a bound buffer must match
+    ctx.bind_accum(t.data_ptr(), res[0] * res[1])
+    try:
+        ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+        ctx.render(1, 1, 1)
+        ctx.render(2, 1, 1)
+        ctx.synchronize()
+        got = t.cpu().numpy().reshape(res[1], res[0], 4)
+    finally:
+        ctx.bind_accum(0, 0)
+    assert np.all(got[..., 3] == 2.0)
+    acc, _, _ = render(ctx, s, res, [(1, 2)], flags=device.FLAG_STAGED)
+    assert np.array_equal(got, acc)
+    for r in ((64, 64), (24, 40)):
+        acc1, _, _ = render(ctx, s, r, [(1, 1), (2, 1)])
+        acc0, _, _ = render(ctx, s, r, [(1, 2)], flags=device.FLAG_STAGED)
+        assert np.array_equal(acc0, acc1)

@@ -353,3 +353,29 @@ def test_coincident_instances_resolve_ties_by_primitive_order(monkeypatch, walk)
         assert np.all(q["prim"][q["tri"] >= 0] < 200)      # always the first copy
     finally:
         c.close()
+
+
+def test_resize_without_a_render_gives_an_empty_image_not_the_old_buffer():
+    """update_resolution (main.rs:79-94) replaces `screen` at once.  After set_frame_uniforms with a
+    LARGER resolution and before any render, read_accum and resolve must see a zeroed accumulator of
+    the new size, never the old, smaller allocation."""
+    s = procedural.box_scene(env_size=(64, 32))
+    a = s.arrays()
+    c = device.Context(0)
+    try:
+        c.upload_scene(a)
+        c.set_frame_uniforms(s.frame_uniforms((32, 16), frame=1, reject_hist=1))
+        c.render(1, 2, 1, device.default_params())
+        assert np.all(c.read_accum()[..., 3] == 2.0)
+        c.set_frame_uniforms(s.frame_uniforms((640, 480), frame=1, reject_hist=0))
+        img = c.resolve()
+        assert img.shape == (480, 640, 4) and np.all(img[..., :3] == 0) and np.all(img[..., 3] == 255)
+        acc = c.read_accum()
+        assert acc.shape == (480, 640, 4) and not acc.any()
+        c.render(1, 1, 1, device.default_params())
+        assert np.all(c.read_accum()[..., 3] == 1.0)
+        # and back down: again the new size, empty
+        c.set_frame_uniforms(s.frame_uniforms((24, 24), frame=1, reject_hist=0))
+        assert not c.read_accum().any()
+    finally:
+        c.close()

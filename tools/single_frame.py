@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Where one 1-spp frame per call (what the reference's frame() does, main.rs:356-407) spends its
 time: wall time per call and HIP-event time per stage, for the headline workload.
-    python tools/single_frame.py [--frames 1] [--calls 20] [bench.py workload arguments]"""
+    python tools/single_frame.py [--frames 1] [--calls 20] [--staged] [bench.py workload arguments]
+--staged sends the call through the staged pipeline (RTHIP_FLAG_STAGED) instead of the single launch
+that calls of one to three frames get."""
 import json
 import os
 import sys
@@ -15,6 +17,9 @@ import bench  # noqa: E402
 def main():
     argv = sys.argv[1:]
     frames, calls = 1, 20
+    staged = "--staged" in argv
+    if staged:
+        argv.remove("--staged")
     for name in ("--frames", "--calls"):
         if name in argv:
             i = argv.index(name)
@@ -33,8 +38,9 @@ def main():
     ctx.upload_scene(arrays)
     ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
     base = dict(max_bounces=args.max_bounces, term_prob=args.term_prob, stack_depth=args.stack_depth)
-    bare = device.default_params(**base)
-    timed = device.default_params(flags=device.FLAG_TIMING, **base)
+    extra = device.FLAG_STAGED if staged else 0
+    bare = device.default_params(flags=extra, **base)
+    timed = device.default_params(flags=device.FLAG_TIMING | extra, **base)
     for f in range(3):
         ctx.render(1 + f * frames, frames, 1, bare)
     ctx.synchronize()
@@ -47,7 +53,7 @@ def main():
     for f in range(calls):
         ctx.render(100 + f * frames, frames, 1, timed)
     t = ctx.timing()
-    out = {"workload": name, "frames_per_call": frames, "wall_ms_per_call": round(wall, 4),
+    out = {"workload": name, "frames_per_call": frames, "staged": staged, "wall_ms_per_call": round(wall, 4),
            "stage_ms_per_call": {s: round(v["ms"] / calls, 4) for s, v in t.items() if v["launches"]},
            "stage_sum_ms": round(sum(v["ms"] for v in t.values()) / calls, 4)}
     print(json.dumps(out))
