@@ -46,6 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--stack-depth", type=int, default=23)
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--tex", type=int, default=1024)
+    ap.add_argument("--textures", default="sponza", choices=("sponza", "light"),
+                    help="atrium: 'sponza' = an albedo, a metallic-roughness and a normal map per material (93 textures, 390 MB at --tex 1024); "
+                         "'light' = the earlier dressing (10 shared textures, 36 MB)")
     ap.add_argument("--tiles", type=int, default=1)
     ap.add_argument("--terrain-n", type=int, default=60)
     ap.add_argument("--view", default="ground", choices=("ground", "top"), help="terrain camera: near the first tiles, or looking down on the whole tiling")
@@ -124,6 +127,8 @@ def workload_key(args):
         k += f"-t{args.tiles}-{args.view}" + ("-inst" if args.instanced else "") + ("-shuf" if args.shuffled else "")
     if args.workload == "atrium" and (args.detail != 1.0 or args.tex != 1024):
         k += f"-d{args.detail}-x{args.tex}"
+    if args.workload == "atrium" and args.textures != "sponza":
+        k += f"-{args.textures}"
     if args.term_prob != 0.5:
         k += f"-p{args.term_prob}"
     if args.opaque:
@@ -152,7 +157,7 @@ def build_workload(args):
             scene.add_camera(host.Camera.default())
         return scene, f"baked scene {os.path.basename(args.scene)}"
     if args.workload == "atrium":
-        scene = procedural.atrium_scene(detail=args.detail, tex=args.tex)
+        scene = procedural.atrium_scene(detail=args.detail, tex=args.tex, textures=args.textures)
         name = "sponza-proxy atrium (procedural; Khronos Sponza is not shipped with the reference)"
     elif args.workload == "blob":
         scene = procedural.blob_scene()
@@ -445,6 +450,8 @@ def main():
                 "primitives": int(arrays["prims"].shape[0]),
                 "nodes": int(arrays["nodes"].shape[0]),
                 "texture_mb": round(arrays["texels"].nbytes / 1e6, 1),
+                "textures": int(len({(int(o), int(z)) for ref in ("albedo", "emissive", "normal", "metallic_roughness")
+                                     for o, z in zip(arrays["prims"]["material"][ref]["offset"], arrays["prims"]["material"][ref]["size"]) if z})),
                 "resolution": f"{res[0]}x{res[1]}",
                 "spp_per_step": 1,
                 "max_bounces": args.max_bounces,

@@ -126,10 +126,14 @@ int add_texture(Scene& s, const uint8_t* rgba8, uint32_t w, uint32_t h, TexRef* 
     if (s.texels.size() + n > 0xFFFFFFFFull) { set_error("add_texture: texel offset overflows u32"); return RTHOST_ERR_LIMIT; }
     out->offset = (uint32_t)s.texels.size();
     out->size = (w << 16) | h;
-    s.texels.reserve(s.texels.size() + n);
+    // the atlas grows geometrically: an exact reserve per texture would copy it once per texture
+    const size_t at = s.texels.size();
+    if (s.texels.capacity() < at + n) s.texels.reserve(std::max<size_t>(at + n, s.texels.capacity() * 2));
+    s.texels.resize(at + n);
+    uint32_t* dst = s.texels.data() + at;
     for (uint64_t i = 0; i < n; i++) { // scene.rs:290-297
         const uint8_t* p = rgba8 + i * 4;
-        s.texels.push_back(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]);
+        dst[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
     }
     return RTHOST_OK;
 }

@@ -37,15 +37,15 @@
 #define RT_PATH_HEAVY_LANES 24
 #endif
 #ifndef RT_PATH_HEAVY_DIV
-#define RT_PATH_HEAVY_DIV 3u
-#endif
-// a wave with at most this many lanes at traversal work stops voting: every lane steps every round
-#ifndef RT_PATH_UNIFIED_LANES
-#define RT_PATH_UNIFIED_LANES 16u
+#define RT_PATH_HEAVY_DIV 2u
 #endif
 #ifndef RT_PATH_RUN_SLOTS
 #define RT_PATH_RUN_SLOTS 64u
 #endif
+
+// iterations after which a wave gives up and reports (a bound on the kernel's only unbounded loop: a
+// wave does a few thousand per frame; the bound is reached after seconds, not minutes)
+#define RT_PATH_WATCHDOG (1u << 23)
 
 struct PathArgs {
     SceneDev  sc;
@@ -67,6 +67,7 @@ struct PathArgs {
     int32_t*  tap_prim;
     float*    tap_t;
     uint32_t* tap_seed;
+    uint32_t* watchdog;       // set to 1 by a wave that ran into RT_PATH_WATCHDOG
     unsigned long long* counters;
     unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped; // see ExtArgs
 #ifdef RT_PROBE
@@ -95,14 +96,13 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     unsigned long long r_prim = 0, r_inner = 0, r_leaf = 0, r_batch = 0; // wave-uniform
     ShadeCounts cnt;
 
-    uint32_t run_next = 0, run_end = 0, cursor_seen = 0;
+    uint32_t run_next = 0, run_end = 0, cursor_seen = 0, iter = 0;
     bool drained = false;
 #ifdef RT_PROBE
     const unsigned long long pr_start = wall_clock64();
     unsigned long long pr_drain = 0, pr_lanes = 0, pr_lanes_tail = 0;
     uint32_t pr_trav = 0, pr_shade = 0, pr_scan = 0, pr_refill = 0, pr_tail = 0, pr_shade_lanes = 0, pr_scan_lanes = 0;
-    unsigned long long pr_heavy_ticks = 0;
-    uint32_t pr_unified = 0;
+    unsigned long long pr_heavy_ticks = 0, pr_ticks_shade = 0, pr_ticks_camera = 0;
 #endif
 
     // per-lane: the path
@@ -287,6 +287,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     };
 
     for (;;) {
+        if (++iter > RT_PATH_WATCHDOG) { // cannot happen; a bound on the loop all the same
+            if (lane == 0) *a.watchdog = 1u;
+            break;
+        }
         const uint32_t n_prim = (uint32_t)__popcll(__ballot(st == ST_PRIM));
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(st == ST_INNER));
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(st == ST_LEAF));
@@ -337,6 +341,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                     st = ST_DONE;
                 }
             }
+#ifdef RT_PROBE
+            const unsigned long long pr_t1 = wall_clock64();
+            pr_ticks_shade += pr_t1 - pr_t0;
+#endif
             // new camera paths for the lanes without a path (those that just ended theirs included)
             if (!drained) {
                 const unsigned long long done_m = __ballot(st == ST_DONE);
@@ -378,41 +386,56 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                 }
             }
             if (fresh) begin_ray(o, d);
-            // candidate masks of the new rays (k_cull's loop: wave-uniform over the primitives)
-            const bool mine = st == ST_SCAN;
-            if (__ballot(mine) != 0ull) {
 #ifdef RT_PROBE
-                pr_scan++; pr_scan_lanes += (uint32_t)__popcll(__ballot(mine));
+            pr_ticks_camera += wall_clock64() - pr_t1;
 #endif
+            // candidate masks of the new rays (k_cull's loop: wave-uniform over the primitives)
+            // Candidate masks of the new rays (k_cull's test on the same padded bounds), one ray at a
+            // time against all primitives, one or two primitives per LANE: the ray's reciprocal
+            // direction and scaled origin are broadcast, every lane tests its primitives, and a
+            // ballot per 64 primitives is the mask.  2 tests per ray and lane instead of n_prims
+            // tests per lane of a wave that is a third full; two rays per turn for two independent
+            // dependency chains.
+            const bool mine = st == ST_SCAN;
+            unsigned long long todo = __ballot(mine);
+            if (todo != 0ull) {
+#ifdef RT_PROBE
+                pr_scan++; pr_scan_lanes += (uint32_t)__popcll(todo);
+#endif
+                float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
+                const bool have0 = lane < sc.n_prims, have1 = lane + 64u < sc.n_prims;
+                if (have0) {
+                    const float4 x = reinterpret_cast<const float4*>(sc.pbounds)[2u * lane], y = reinterpret_cast<const float4*>(sc.pbounds)[2u * lane + 1u];
+                    b0[0] = x.x; b0[1] = x.y; b0[2] = x.z; b0[3] = x.w; b0[4] = y.x; b0[5] = y.y;
+                }
+                if (have1) {
+                    const float4 x = reinterpret_cast<const float4*>(sc.pbounds)[2u * (lane + 64u)], y = reinterpret_cast<const float4*>(sc.pbounds)[2u * (lane + 64u) + 1u];
+                    b1[0] = x.x; b1[1] = x.y; b1[2] = x.z; b1[3] = x.w; b1[4] = y.x; b1[5] = y.y;
+                }
                 f3 oi, idir;
                 world_test_ray(o, d, oi, idir);
-                uint32_t m[4];
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    uint32_t mw = 0;
-#pragma unroll 1
-                    for (uint32_t gg = 0; gg < 4u; gg++) {
-                        const uint32_t g = 4u * w + gg;
-                        if (g >= sc.n_prim_groups) break;
-                        const rt_float8 u = *(rt_cfloat8_p)(sc.gbounds + (size_t)g * 8u);
-                        const float ub[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
-                        if (__ballot(mine && overlaps_world_box(oi, idir, ub)) == 0ull) continue;
-                        const rt_cfloat8_p bp = (rt_cfloat8_p)(sc.wbounds + (size_t)g * 48u);
-                        const rt_float8 lx = bp[0], ly = bp[1], lz = bp[2], hx = bp[3], hy = bp[4], hz = bp[5];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const float b[6] = {lx[k], ly[k], lz[k], hx[k], hy[k], hz[k]};
-                            mw |= (overlaps_world_box(oi, idir, b) ? 1u : 0u) << (gg * 8u + k);
-                        }
+                auto bcast = [&](float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+                while (todo) {
+                    const int s0 = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const int s1 = todo ? (int)__builtin_ctzll(todo) : s0; // a second ray in the same turn (the first again when none is left)
+                    todo &= todo - 1ull;
+                    const f3 oi0 = F3(bcast(oi.x, s0), bcast(oi.y, s0), bcast(oi.z, s0)), id0 = F3(bcast(idir.x, s0), bcast(idir.y, s0), bcast(idir.z, s0));
+                    const f3 oi1 = F3(bcast(oi.x, s1), bcast(oi.y, s1), bcast(oi.z, s1)), id1 = F3(bcast(idir.x, s1), bcast(idir.y, s1), bcast(idir.z, s1));
+                    const unsigned long long lo0 = __ballot(have0 && overlaps_world_box(oi0, id0, b0));
+                    const unsigned long long lo1 = __ballot(have0 && overlaps_world_box(oi1, id1, b0));
+                    const unsigned long long hi0 = __ballot(have1 && overlaps_world_box(oi0, id0, b1));
+                    const unsigned long long hi1 = __ballot(have1 && overlaps_world_box(oi1, id1, b1));
+                    if ((int)lane == s0) {
+                        mask[0] = (uint32_t)lo0; mask[1] = (uint32_t)(lo0 >> 32);
+                        mask[2] = (uint32_t)hi0; mask[3] = (uint32_t)(hi0 >> 32);
                     }
-                    const uint32_t first = 32u * w;
-                    const uint32_t have = sc.n_prims > first ? min(sc.n_prims - first, 32u) : 0u;
-                    m[w] = have >= 32u ? mw : (mw & ((1u << have) - 1u));
+                    if ((int)lane == s1) {
+                        mask[0] = (uint32_t)lo1; mask[1] = (uint32_t)(lo1 >> 32);
+                        mask[2] = (uint32_t)hi1; mask[3] = (uint32_t)(hi1 >> 32);
+                    }
                 }
-                if (mine) {
-                    mask[0] = m[0]; mask[1] = m[1]; mask[2] = m[2]; mask[3] = m[3];
-                    advance();
-                }
+                if (mine) advance();
             }
 #ifdef RT_PROBE
             pr_heavy_ticks += wall_clock64() - pr_t0;
@@ -426,40 +449,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         if (drained) { pr_tail++; pr_lanes_tail += n_trav; }
 #endif
 
-        if (n_trav <= RT_PATH_UNIFIED_LANES) {
-            // ---- thin wave (its paths are running out): every lane takes its next step, whatever
-            // its kind.  One set of fetches at the lane's sibling pair, triangles or primitive
-            // record, one wait, then the three step bodies under their masks.  The plurality vote
-            // below serves one kind per round; with a dozen lanes left that leaves most of them
-            // waiting, and the end of the launch is the time its last rays need.
-#ifdef RT_PROBE
-            pr_unified++;
-#endif
-            const bool is_inner = st == ST_INNER, is_leaf = st == ST_LEAF, is_prim = st == ST_PRIM;
-            const bool two = is_leaf && cur_count > 1u;
-            if (COUNT) { if (__ballot(is_inner)) r_inner++; if (__ballot(is_leaf)) r_leaf += __ballot(two) ? 2u : 1u; if (__ballot(is_prim)) r_prim++; }
-            uint32_t p = 0;
-            const float4* base = rec16(sc.pairs, cur_first * 2u);
-            if (is_leaf) base = rec16(tris, cur_first * 3u);
-            if (is_prim) {
-                p = next_candidate();
-                base = rec16(sc.primx, p * (uint32_t)(sizeof(PrimX) / 16));
-            }
-            float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
-            if (is_inner || is_leaf || is_prim) { q0 = base[0]; q1 = base[1]; q2 = base[2]; }
-            if (is_inner) { const uint2 dd = *reinterpret_cast<const uint2*>(base + 3); q3.x = __uint_as_float(dd.x); q3.y = __uint_as_float(dd.y); }
-            if (is_prim || two) { q3 = base[3]; q4 = base[4]; }
-            if (two) q5 = base[5];
-            if (is_inner) {
-                inner_step(q0, q1, q2, make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y)));
-            } else if (is_leaf) {
-                rt_float3 a0 = {q0.x, q0.y, q0.z}, a1 = {q1.x, q1.y, q1.z}, a2 = {q2.x, q2.y, q2.z};
-                rt_float3 b0 = {q3.x, q3.y, q3.z}, b1 = {q4.x, q4.y, q4.z}, b2 = {q5.x, q5.y, q5.z};
-                leaf_step(a0, a1, a2, b0, b1, b2, two);
-            } else if (is_prim) {
-                prim_step(p, q0, q1, q2, q3, q4);
-            }
-        } else if (n_inner >= n_prim && n_inner >= n_leaf) {
+        if (n_inner >= n_prim && n_inner >= n_leaf) {
 #pragma unroll 1
             for (int burst = 0; burst < RT_INNER_BURST; burst++) {
                 if (COUNT) r_inner++;
@@ -496,10 +486,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         unsigned long long* r = a.probe + 8ull * ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6));
         r[0] = pr_start; r[1] = pr_drain; r[2] = wall_clock64();
         r[3] = pr_trav | ((unsigned long long)pr_tail << 32);                  // traversal rounds: all, after the drain
-        r[4] = pr_lanes | ((unsigned long long)pr_unified << 40);                                                       // lanes with traversal work, summed over those rounds
+        r[4] = pr_lanes | ((pr_ticks_shade >> 4) << 40);                                                       // lanes with traversal work, summed over those rounds
         r[5] = pr_lanes_tail | (pr_heavy_ticks << 32);                         // ... after the drain; ticks spent in path rounds
         r[6] = pr_shade | ((unsigned long long)pr_shade_lanes << 32);
-        r[7] = pr_scan | ((unsigned long long)pr_scan_lanes << 32) | ((unsigned long long)pr_refill << 48);
+        r[7] = pr_scan | ((unsigned long long)(pr_ticks_camera >> 4) << 32);
     }
 #endif
     if (COUNT) {

@@ -119,6 +119,8 @@ struct rthip_ctx {
 
     unsigned long long* d_counters = nullptr;
 
+    uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
+    uint32_t* watchdog_dev = nullptr;  // the same word as the device sees it
     unsigned char* noalloc_scratch = nullptr; // this device's copy of `scratch` (rthip_trace_rays_noalloc)
     // grow-only staging of rthip_trace_rays and rthip_resolve
     float4*   tr_q = nullptr;
@@ -394,6 +396,16 @@ void extend_launch(bool count, bool deep, ExtMode m, uint32_t grid, hipStream_t 
 }
 
 
+// After the stream is drained: did a kernel run into the bound on its loops?  (It cannot by
+// construction; the bound is there so that a defect ends as an error code and not as a hung GPU.)
+int check_watchdog(rthip_ctx* c) {
+    if (c->watchdog_host && *const_cast<volatile uint32_t*>(c->watchdog_host) != 0u) {
+        *c->watchdog_host = 0u;
+        return fail(c, RTHIP_ERR_HIP, "a wave of the path kernel gave up at its iteration bound: the image of the last render is incomplete");
+    }
+    return RTHIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -428,6 +440,15 @@ int rthip_create(int device_ordinal, rthip_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(Counters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(Counters));
     if (e != hipSuccess) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    // a pinned host word the device can write: a kernel whose bounded loop ran out says so here, and
+    // the calls that synchronise report it (without it short calls keep the staged pipeline)
+    if (hipHostMalloc((void**)&c->watchdog_host, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        *c->watchdog_host = 0u;
+        if (hipHostGetDevicePointer((void**)&c->watchdog_dev, c->watchdog_host, 0) != hipSuccess) c->watchdog_dev = nullptr;
+    } else {
+        c->watchdog_host = nullptr;
+        (void)hipGetLastError();
+    }
     // every GPU holds its own copy of the static work array at its own address
     e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !c->noalloc_scratch) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
@@ -445,6 +466,7 @@ void rthip_destroy(rthip_ctx* c) {
     free_frame_buffers(c);
     free_dev_t(c->ctrl);
     free_dev_t(c->d_counters);
+    if (c->watchdog_host) (void)hipHostFree(c->watchdog_host);
     free_dev_t(c->tr_q); free_dev_t(c->tr_hits); free_dev_t(c->tr_lists); free_dev_t(c->resolve_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1091,7 +1113,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         // (rt_path.h): the staged pipeline below would spend most of such a call in the tails of its
         // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk and
         // stacks that fit the LDS column only.
-        const bool fused = !staged_only && nf <= RT_PATH_MAX_FRAMES && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun;
+        const bool fused = !staged_only && nf <= RT_PATH_MAX_FRAMES && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun &&
+                           c->watchdog_dev != nullptr;
         if (fused) {
             PathArgs pa{};
             pa.sc = c->sc;
@@ -1123,6 +1146,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             int pblocks = count ? occupancy_blocks(k_path<true>, 256) : occupancy_blocks(k_path<false>, 256);
             if (path_blocks_env > 0) pblocks = std::min(pblocks, path_blocks_env);
             const uint32_t pgrid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * pblocks, (slots + 255) / 256);
+            pa.watchdog = c->watchdog_dev;
 #ifdef RT_PROBE
             // diagnostic build only (tools/path_probe.py): per-wave records of this launch appended to $RTHIP_PROBE_FILE
             static unsigned long long* path_probe_buf = nullptr;
@@ -1554,7 +1578,7 @@ int rthip_read_accum(rthip_ctx* c, float* rgba, uint64_t n_pixels) {
     if (rc != RTHIP_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(rgba, c->accum, sizeof(float4) * n_pixels, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return RTHIP_OK;
+    return check_watchdog(c);
 }
 
 int rthip_write_accum(rthip_ctx* c, const float* rgba, uint64_t n_pixels) {
@@ -1641,7 +1665,7 @@ int rthip_resolve(rthip_ctx* c, uint8_t* rgba8, uint64_t n_pixels, int apply_srg
     hipError_t e = hipMemcpyAsync(rgba8, d_out, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "resolve: %s", hipGetErrorString(e));
-    return RTHIP_OK;
+    return check_watchdog(c);
 }
 
 int rthip_get_counters(rthip_ctx* c, rthip_counters* out) {
@@ -1718,7 +1742,7 @@ int rthip_synchronize(rthip_ctx* c) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return RTHIP_OK;
+    return check_watchdog(c);
 }
 
 } // extern "C"

@@ -148,40 +148,41 @@ def merge(meshes):
 
 
 def _value_noise(h, w, cells, rng):
-    g = rng.random((cells + 1, cells + 1))
-    ys = np.linspace(0, cells, h, endpoint=False)
-    xs = np.linspace(0, cells, w, endpoint=False)
-    y0, x0 = ys.astype(int), xs.astype(int)
+    """Smooth value noise in [0, 1): a (cells + 1)^2 lattice of random values, smoothstep-interpolated
+    (along x first, then along y: two gathers of the full size instead of four)."""
+    g = rng.random((cells + 1, cells + 1)).astype(np.float32)
+    ys = np.linspace(0, cells, h, endpoint=False, dtype=np.float32)
+    xs = np.linspace(0, cells, w, endpoint=False, dtype=np.float32)
+    y0, x0 = ys.astype(np.intp), xs.astype(np.intp)
     fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
     fy, fx = fy * fy * (3 - 2 * fy), fx * fx * (3 - 2 * fx)
-    a, b = g[y0][:, x0], g[y0][:, x0 + 1]
-    c, d = g[y0 + 1][:, x0], g[y0 + 1][:, x0 + 1]
-    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+    gx = g[:, x0] * (1 - fx) + g[:, x0 + 1] * fx            # (cells + 1, w)
+    return gx[y0] * (1 - fy) + gx[y0 + 1] * fy
 
 
 def texture_stone(size, seed, tint=(0.75, 0.7, 0.62)):
     rng = np.random.default_rng(seed)
-    n = 0.5 * _value_noise(size, size, 8, rng) + 0.3 * _value_noise(size, size, 32, rng) + \
-        0.2 * _value_noise(size, size, 128, rng)
-    yy, xx = np.mgrid[0:size, 0:size]
+    n = np.float32(0.5) * _value_noise(size, size, 8, rng) + np.float32(0.3) * _value_noise(size, size, 32, rng) + \
+        np.float32(0.2) * _value_noise(size, size, 128, rng)
+    yy, xx = np.arange(size)[:, None], np.arange(size)[None, :]
     mortar = ((yy % (size // 8) < 3) | ((xx + (yy // (size // 8)) * (size // 16)) % (size // 4) < 3))
-    v = np.clip(0.35 + 0.65 * n, 0, 1) * np.where(mortar, 0.55, 1.0)
-    img = np.zeros((size, size, 4), np.uint8)
+    v = np.clip(np.float32(0.35) + np.float32(0.65) * n, 0, 1) * np.where(mortar, np.float32(0.55), np.float32(1.0))
+    img = np.empty((size, size, 4), np.uint8)
     for k in range(3):
-        img[..., k] = np.clip(v * tint[k] * 255, 0, 255)
+        img[..., k] = np.clip(v * np.float32(tint[k] * 255), 0, 255)
     img[..., 3] = 255
     return img
 
 
 def texture_fabric(size, seed, tint):
     rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:size, 0:size]
-    weave = 0.5 + 0.25 * np.sin(xx * 2 * np.pi / 8) * np.sin(yy * 2 * np.pi / 8)
-    stripes = 0.75 + 0.25 * np.sign(np.sin(xx * 2 * np.pi / (size / 6)))
-    v = weave * stripes * (0.8 + 0.2 * _value_noise(size, size, 16, rng))
+    yy, xx = np.arange(size, dtype=np.float32)[:, None], np.arange(size, dtype=np.float32)[None, :]
+    weave = np.float32(0.5) + np.float32(0.25) * np.sin(xx * np.float32(2 * np.pi / 8)) * np.sin(yy * np.float32(2 * np.pi / 8))
+    stripes = np.float32(0.75) + np.float32(0.25) * np.sign(np.sin(xx * np.float32(2 * np.pi / (size / 6))))
+    v = weave * stripes * (np.float32(0.8) + np.float32(0.2) * _value_noise(size, size, 16, rng))
     img = np.zeros((size, size, 4), np.uint8)
     for k in range(3):
-        img[..., k] = np.clip(v * tint[k] * 255, 0, 255)
+        img[..., k] = np.clip(v * np.float32(tint[k] * 255), 0, 255)
     img[..., 3] = 255
     return img
 
@@ -189,15 +190,16 @@ def texture_fabric(size, seed, tint):
 def texture_leaves(size, seed):
     """Foliage atlas with a binary-ish alpha channel (for MASK) and soft edges (for BLEND)."""
     rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
-    alpha = np.zeros((size, size))
+    yy, xx = np.arange(size, dtype=np.float32)[:, None], np.arange(size, dtype=np.float32)[None, :]
+    alpha = np.zeros((size, size), np.float32)
     for _ in range(24):
-        cx, cy = rng.random(2) * size
-        a, b = size * (0.05 + 0.08 * rng.random()), size * (0.02 + 0.04 * rng.random())
+        cx, cy = (np.float32(c) for c in rng.random(2) * size)
+        a, b = np.float32(size * (0.05 + 0.08 * rng.random())), np.float32(size * (0.02 + 0.04 * rng.random()))
         th = rng.random() * np.pi
+        cs, sn = np.float32(np.cos(th)), np.float32(np.sin(th))
         dx, dy = xx - cx, yy - cy
-        u, v = dx * np.cos(th) + dy * np.sin(th), -dx * np.sin(th) + dy * np.cos(th)
-        alpha = np.maximum(alpha, np.clip(1.5 - 1.5 * ((u / a) ** 2 + (v / b) ** 2), 0, 1))
+        u, v = dx * cs + dy * sn, dy * cs - dx * sn
+        alpha = np.maximum(alpha, np.clip(np.float32(1.5) - np.float32(1.5) * ((u / a) ** 2 + (v / b) ** 2), 0, 1))
     g = 0.35 + 0.4 * _value_noise(size, size, 16, rng)
     img = np.zeros((size, size, 4), np.uint8)
     img[..., 0] = np.clip(g * 0.45 * 255, 0, 255)
@@ -213,6 +215,38 @@ def texture_metal_rough(size, seed):
     img = np.zeros((size, size, 4), np.uint8)
     img[..., 1] = np.clip((0.2 + 0.6 * _value_noise(size, size, 8, rng)) * 255, 0, 255)
     img[..., 2] = np.where(_value_noise(size, size, 4, rng) > 0.5, 255, 0)
+    img[..., 3] = 255
+    return img
+
+
+def texture_surface_mr(size, seed, roughness=(0.35, 0.95), metal=0.0):
+    """glTF metallic-roughness map of a dielectric or metal surface: G = roughness varying between
+    the two bounds, B = metallic: 0, 255, or (0 < metal < 1) patches covering about that fraction."""
+    rng = np.random.default_rng(seed)
+    n = 0.6 * _value_noise(size, size, 6, rng) + 0.4 * _value_noise(size, size, 48, rng)
+    img = np.zeros((size, size, 4), np.uint8)
+    img[..., 1] = np.clip((roughness[0] + (roughness[1] - roughness[0]) * n) * 255, 0, 255)
+    if metal >= 1.0:
+        img[..., 2] = 255
+    elif metal > 0.0:
+        img[..., 2] = np.where(_value_noise(size, size, 5, rng) < metal, 255, 0)
+    img[..., 3] = 255
+    return img
+
+
+def texture_normal(size, seed, strength=2.0):
+    """Tangent-space normal map from the slopes of a noise height field.  The reference loads a
+    material's normal texture into the atlas (scene.rs:290-341) and never samples it
+    (shader.wgsl:803-881 reads albedo, emissive and metallic-roughness only): it is there for its bytes."""
+    rng = np.random.default_rng(seed)
+    h = 0.7 * _value_noise(size, size, 12, rng) + 0.3 * _value_noise(size, size, 64, rng)
+    gx = (np.roll(h, -1, 1) - np.roll(h, 1, 1)) * strength * size / 64.0
+    gy = (np.roll(h, -1, 0) - np.roll(h, 1, 0)) * strength * size / 64.0
+    nz = 1.0 / np.sqrt(gx * gx + gy * gy + 1.0)
+    img = np.zeros((size, size, 4), np.uint8)
+    img[..., 0] = np.clip((-gx * nz * 0.5 + 0.5) * 255, 0, 255)
+    img[..., 1] = np.clip((-gy * nz * 0.5 + 0.5) * 255, 0, 255)
+    img[..., 2] = np.clip((nz * 0.5 + 0.5) * 255, 0, 255)
     img[..., 3] = 255
     return img
 
@@ -253,7 +287,7 @@ def sky_env(w=1024, h=512, sun_dir=(0.31, 0.25, 0.92), sun_power=60.0):
 
 def material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=1.0, emissive=(0, 0, 0), albedo_tex=None,
              emissive_tex=None, mr_tex=None, albedo_set=0, emissive_set=0, mr_set=0,
-             alpha_mode=L.ALPHA_OPAQUE, alpha_cutoff=0.5):
+             alpha_mode=L.ALPHA_OPAQUE, alpha_cutoff=0.5, normal_tex=None):
     m = L.default_material()
     m["albedo_factor"] = albedo
     m["metallic_factor"], m["roughness_factor"] = metallic, roughness
@@ -264,6 +298,8 @@ def material(albedo=(1, 1, 1, 1), metallic=0.0, roughness=1.0, emissive=(0, 0, 0
         m["emissive"] = emissive_tex
     if mr_tex is not None:
         m["metallic_roughness"] = mr_tex
+    if normal_tex is not None:
+        m["normal"] = normal_tex
     m["albedo_texcoord"], m["emissive_texcoord"], m["metal_r_texcoord"] = albedo_set, emissive_set, mr_set
     m["alpha_settings"] = host.pack_alpha(alpha_mode, alpha_cutoff)
     return m
@@ -396,45 +432,96 @@ def terrain_scene(tiles=1, n=60, env_size=(1024, 512), instanced=False, view="gr
     return s
 
 
-def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
+def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512), textures="sponza"):
     """Sponza-shaped stand-in: a two-storey colonnaded atrium open to the sky, ~262 k triangles
     in 103 primitives (detail = 1), stone / fabric / foliage textures, MASK alpha on foliage and
-    chains, instanced columns, camera on the long axis with depth of field."""
+    chains, instanced columns, camera on the long axis with depth of field.
+
+    textures="sponza" (default) dresses it the way the glTF Sponza is dressed: 31 materials, every
+    one with an albedo map, a metallic-roughness map and a normal map of its own (93 textures of
+    tex x tex texels in the one rgba8 atlas of scene.rs:290-341: 390 MB at tex = 1024; the normal
+    maps are loaded and never sampled, as upstream).  textures="light" is the earlier, lighter
+    dressing (10 textures shared by all materials, a metallic-roughness map on the columns and the
+    basin only), kept so that both can be measured side by side."""
+    assert textures in ("sponza", "light")
+    heavy = textures == "sponza"
     s = host.Scene()
     d = lambda n: max(2, int(round(n * np.sqrt(detail))))
-    stone = [s.add_texture(texture_stone(tex, 10 + k, tint)) for k, tint in
-             enumerate([(0.75, 0.7, 0.62), (0.6, 0.58, 0.55), (0.8, 0.72, 0.6), (0.55, 0.5, 0.45)])]
-    fabric = [s.add_texture(texture_fabric(tex, 20 + k, tint)) for k, tint in
-              enumerate([(0.8, 0.15, 0.12), (0.15, 0.3, 0.75), (0.2, 0.6, 0.25)])]
-    leaves = s.add_texture(texture_leaves(tex, 30))
-    chain_tex = s.add_texture(texture_checker(tex // 2, 16, (200, 190, 160, 255), (0, 0, 0, 0)))
-    mr = s.add_texture(texture_metal_rough(tex // 2, 31))
+    stone_tints = [(0.75, 0.7, 0.62), (0.6, 0.58, 0.55), (0.8, 0.72, 0.6), (0.55, 0.5, 0.45)]
+    fabric_tints = [(0.8, 0.15, 0.12), (0.15, 0.3, 0.75), (0.2, 0.6, 0.25)]
+    if not heavy:
+        stone = [s.add_texture(texture_stone(tex, 10 + k, tint)) for k, tint in enumerate(stone_tints)]
+        fabric = [s.add_texture(texture_fabric(tex, 20 + k, tint)) for k, tint in enumerate(fabric_tints)]
+        leaves = s.add_texture(texture_leaves(tex, 30))
+        chain_tex = s.add_texture(texture_checker(tex // 2, 16, (200, 190, 160, 255), (0, 0, 0, 0)))
+        mr = s.add_texture(texture_metal_rough(tex // 2, 31))
+    made = {}
+
+    def mat(kind, i, light, **kw):
+        """Material i of a kind.  Heavy dressing: its own albedo, metallic-roughness and normal map,
+        made on first use; light dressing: the material the scene used before (light())."""
+        if not heavy:
+            return light()
+        key = (kind, i)
+        if key not in made:
+            seed = 1000 + 37 * len(made)
+            if kind == "stone":
+                t = stone_tints[i % 4]
+                shade = 0.85 + 0.05 * (i % 7)
+                alb = texture_stone(tex, seed, (min(t[0] * shade, 1.0), min(t[1] * shade, 1.0), min(t[2] * shade, 1.0)))
+                mrt = texture_surface_mr(tex, seed + 1, (0.45, 1.0), 0.0)
+            elif kind == "fabric":
+                t = fabric_tints[i % 3]
+                alb = texture_fabric(tex, seed, t if i < 3 else (t[1], t[2], t[0]))
+                mrt = texture_surface_mr(tex, seed + 1, (0.8, 1.0), 0.0)
+            elif kind == "leaves":
+                alb = texture_leaves(tex, seed)
+                mrt = texture_surface_mr(tex, seed + 1, (0.5, 0.9), 0.0)
+            elif kind == "chain":
+                alb = np.kron(texture_checker(tex // 16, 16, (200, 190, 160, 255), (0, 0, 0, 0)), np.ones((16, 16, 1), np.uint8))
+                mrt = texture_surface_mr(tex, seed + 1, (0.25, 0.6), 1.0)
+            elif kind == "metal":
+                alb = texture_stone(tex, seed, (0.95, 0.78, 0.34))
+                mrt = texture_surface_mr(tex, seed + 1, (0.2, 0.5), 1.0)
+            elif kind == "glazed":
+                alb = texture_stone(tex, seed, stone_tints[i % 4])
+                mrt = texture_surface_mr(tex, seed + 1, (0.3, 0.8), 0.5)
+            else:
+                raise ValueError(kind)
+            made[key] = (s.add_texture(alb), s.add_texture(mrt), s.add_texture(texture_normal(tex, seed + 2)))
+        alb, mrt, nrm = made[key]
+        return material(albedo_tex=alb, mr_tex=mrt, normal_tex=nrm, **kw)
 
     L_, W_, H1, H2 = 30.0, 12.0, 5.0, 10.0
     # floor and upper gallery floors
     f = grid(d(186), d(72), (L_, W_), uv_scale=10.0)
-    s.add_primitive(f[0], f[1], normals=f[2], uv0=f[3], material=material(albedo_tex=stone[0], roughness=0.6))
-    for side in (-1, 1):
+    s.add_primitive(f[0], f[1], normals=f[2], uv0=f[3],
+                    material=mat("stone", 0, lambda: material(albedo_tex=stone[0], roughness=0.6), roughness=0.75))
+    for k, side in enumerate((-1, 1)):
         g = grid(d(96), d(12), (L_, 3.0), uv_scale=6.0)
-        s.add_primitive(g[0], g[1], normals=g[2], uv0=g[3], material=material(albedo_tex=stone[1], roughness=0.8),
+        s.add_primitive(g[0], g[1], normals=g[2], uv0=g[3],
+                        material=mat("stone", 1 + k, lambda: material(albedo_tex=stone[1], roughness=0.8), roughness=0.9),
                         transform=host.trs((0.0, side * (W_ / 2 - 1.5), H1)))
     # outer walls (4), two storeys
-    for side in (-1, 1):
+    for k, side in enumerate((-1, 1)):
         w = grid(d(110), d(40), (L_, H2), uv_scale=8.0)
-        s.add_primitive(w[0], w[1], normals=w[2], uv0=w[3], material=material(albedo_tex=stone[2], roughness=0.9),
+        s.add_primitive(w[0], w[1], normals=w[2], uv0=w[3],
+                        material=mat("stone", 3 + k, lambda: material(albedo_tex=stone[2], roughness=0.9), roughness=1.0),
                         transform=host.trs((0.0, side * W_ / 2, H2 / 2), rot_x=side * np.pi / 2))
         e = grid(d(48), d(40), (W_, H2), uv_scale=8.0)
-        s.add_primitive(e[0], e[1], normals=e[2], uv0=e[3], material=material(albedo_tex=stone[3], roughness=0.9),
+        s.add_primitive(e[0], e[1], normals=e[2], uv0=e[3],
+                        material=mat("stone", 5 + k, lambda: material(albedo_tex=stone[3], roughness=0.9), roughness=1.0),
                         transform=host.basis((side * L_ / 2, 0.0, H2 / 2), (0, 1, 0), (0, 0, 1), (1, 0, 0)))
     # columns: one unique mesh per storey and side, instanced along the nave
     flute = lambda z: 1.0 + 0.25 * np.exp(-40 * z * z) + 0.3 * np.exp(-40 * (1 - z) ** 2) - 0.06 * z
     n_cols = 9
     for storey, (z0, hh, rad) in enumerate(((0.0, H1, 0.38), (H1, H2 - H1 - 0.5, 0.3))):
-        for side in (-1, 1):
+        for k, side in enumerate((-1, 1)):
             c = cylinder(d(48), d(40), rad, hh, flute)
             y = side * (W_ / 2 - 3.0)
             first = s.add_primitive(c[0], c[1], normals=c[2], uv0=c[3],
-                                    material=material(albedo_tex=stone[(storey + 1) % 4], mr_tex=mr, roughness=0.7),
+                                    material=mat("glazed", 2 * storey + k,
+                                                 lambda: material(albedo_tex=stone[(storey + 1) % 4], mr_tex=mr, roughness=0.7), roughness=0.9),
                                     transform=host.trs((-L_ / 2 + 2.0, y, z0)))
             for k in range(1, n_cols):
                 s.add_instance(first, host.trs((-L_ / 2 + 2.0 + k * (L_ - 4.0) / (n_cols - 1), y, z0), rot_z=0.37 * k))
@@ -443,7 +530,8 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
         for k in range(n_cols - 1):
             a = torus(d(28), d(12), R=(L_ - 4.0) / (n_cols - 1) / 2, r=0.22, arc=np.pi)
             x = -L_ / 2 + 2.0 + (k + 0.5) * (L_ - 4.0) / (n_cols - 1)
-            s.add_primitive(a[0], a[1], normals=a[2], uv0=a[3], material=material(albedo_tex=stone[k % 4], roughness=0.8),
+            s.add_primitive(a[0], a[1], normals=a[2], uv0=a[3],
+                            material=mat("stone", 7 + k % 4, lambda: material(albedo_tex=stone[k % 4], roughness=0.8), roughness=0.9),
                             transform=host.trs((x, side * (W_ / 2 - 3.0), H1 - 1.7), rot_x=np.pi / 2))
     # hanging curtains (wavy cloth), three fabrics
     for k in range(6):
@@ -451,7 +539,8 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
         cl = grid(d(84), d(84), (3.2, 3.0), height=wave, uv_scale=2.0)
         side = -1 if k % 2 else 1
         s.add_primitive(cl[0], cl[1], normals=cl[2], uv0=cl[3], uv1=cl[3] * 3.0,
-                        material=material(albedo_tex=fabric[k % 3], albedo_set=k % 2, roughness=0.95),
+                        material=mat("fabric", k, lambda: material(albedo_tex=fabric[k % 3], albedo_set=k % 2, roughness=0.95),
+                                     albedo_set=k % 2, mr_set=k % 2, roughness=1.0),
                         transform=host.trs((-9.0 + 3.6 * k, side * (W_ / 2 - 3.0), H1 + 1.8), rot_x=np.pi / 2))
     # potted plants: MASK-alpha leaf cards
     rng = np.random.default_rng(5)
@@ -465,39 +554,47 @@ def atrium_scene(detail=1.0, tex=512, env_size=(1024, 512)):
         pm = merge(cards)
         x = -11.0 + 3.1 * k
         s.add_primitive(pm[0], pm[1], normals=pm[2], uv0=pm[3],
-                        material=material(albedo_tex=leaves, alpha_mode=L.ALPHA_MASK, alpha_cutoff=0.5, roughness=0.7),
+                        material=mat("leaves", k % 2, lambda: material(albedo_tex=leaves, alpha_mode=L.ALPHA_MASK, alpha_cutoff=0.5, roughness=0.7),
+                                     alpha_mode=L.ALPHA_MASK, alpha_cutoff=0.5, roughness=0.9),
                         transform=host.trs((x, (1 if k % 2 else -1) * 1.6, 0.0)))
         pot = cylinder(d(24), d(6), 0.45, 0.9, lambda z: 0.7 + 0.3 * z)
-        s.add_primitive(pot[0], pot[1], normals=pot[2], uv0=pot[3], material=material(albedo_tex=stone[3], roughness=0.5),
+        s.add_primitive(pot[0], pot[1], normals=pot[2], uv0=pot[3],
+                        material=mat("glazed", 4, lambda: material(albedo_tex=stone[3], roughness=0.5), roughness=0.6),
                         transform=host.trs((x, (1 if k % 2 else -1) * 1.6, 0.0)))
     # sculpted heads at both ends (dense meshes)
-    for side in (-1, 1):
+    for k, side in enumerate((-1, 1)):
         bump = lambda p: 1.0 + 0.12 * np.sin(9 * p[:, 0]) * np.sin(8 * p[:, 1]) * np.sin(7 * p[:, 2]) + 0.2 * np.exp(-6 * (p[:, 0] - side * 0.8) ** 2)
         hd = uv_sphere(d(160), d(118), radius=1.3, displace=bump)
-        s.add_primitive(hd[0], hd[1], normals=hd[2], uv0=hd[3], material=material(albedo=(0.85, 0.7, 0.3, 1), metallic=1.0, roughness=0.35),
+        s.add_primitive(hd[0], hd[1], normals=hd[2], uv0=hd[3],
+                        material=mat("metal", k, lambda: material(albedo=(0.85, 0.7, 0.3, 1), metallic=1.0, roughness=0.35), roughness=0.8),
                         transform=host.trs((side * (L_ / 2 - 2.0), 0.0, 2.2)))
         ped = box((0.9, 0.9, 0.5))
-        s.add_primitive(ped[0], ped[1], normals=ped[2], uv0=ped[3], material=material(albedo_tex=stone[1], roughness=0.6),
+        s.add_primitive(ped[0], ped[1], normals=ped[2], uv0=ped[3],
+                        material=mat("stone", 11, lambda: material(albedo_tex=stone[1], roughness=0.6), roughness=0.7),
                         transform=host.trs((side * (L_ / 2 - 2.0), 0.0, 0.5)))
     # chains with MASK alpha and hanging lamps (emissive)
     for k in range(4):
         ch = cylinder(d(12), d(40), 0.05, 3.0)
         x = -9.0 + 6.0 * k
         s.add_primitive(ch[0], ch[1], normals=ch[2], uv0=ch[3] * np.array([1.0, 6.0], np.float32),
-                        material=material(albedo_tex=chain_tex, alpha_mode=L.ALPHA_MASK, alpha_cutoff=0.5, metallic=1.0, roughness=0.4),
+                        material=mat("chain", 0, lambda: material(albedo_tex=chain_tex, alpha_mode=L.ALPHA_MASK, alpha_cutoff=0.5, metallic=1.0, roughness=0.4),
+                                     alpha_mode=L.ALPHA_MASK, alpha_cutoff=0.5, roughness=1.0),
                         transform=host.trs((x, 0.0, H2 - 3.5)))
         lamp = uv_sphere(d(24), d(16), radius=0.35)
         s.add_primitive(lamp[0], lamp[1], normals=lamp[2], uv0=lamp[3],
-                        material=material(albedo=(0.9, 0.9, 0.9, 1), emissive=(8.0, 6.0, 3.5), roughness=0.9),
+                        material=mat("stone", 12, lambda: material(albedo=(0.9, 0.9, 0.9, 1), emissive=(8.0, 6.0, 3.5), roughness=0.9),
+                                     emissive=(8.0, 6.0, 3.5), roughness=1.0),
                         transform=host.trs((x, 0.0, H2 - 3.8)))
     # central basin
     bs = torus(d(96), d(24), R=1.6, r=0.35)
-    s.add_primitive(bs[0], bs[1], normals=bs[2], uv0=bs[3], material=material(albedo_tex=stone[0], mr_tex=mr, roughness=0.5),
+    s.add_primitive(bs[0], bs[1], normals=bs[2], uv0=bs[3],
+                    material=mat("glazed", 5, lambda: material(albedo_tex=stone[0], mr_tex=mr, roughness=0.5), roughness=0.7),
                     transform=host.trs((0.0, 0.0, 0.35)))
     # roof beams across the opening
     for k in range(9):
         bm = box((0.15, W_ / 2, 0.2))
-        s.add_primitive(bm[0], bm[1], normals=bm[2], uv0=bm[3], material=material(albedo_tex=stone[2], roughness=0.9),
+        s.add_primitive(bm[0], bm[1], normals=bm[2], uv0=bm[3],
+                        material=mat("stone", 13, lambda: material(albedo_tex=stone[2], roughness=0.9), roughness=1.0),
                         transform=host.trs((-L_ / 2 + 3.0 + 3.0 * k, 0.0, H2 + 0.2)))
     s.set_env(sky_env(*env_size))
     s.add_camera(host.Camera.look((-9.5, -0.6, 1.9), yaw=0.04, pitch=np.radians(6), fovy=np.radians(62), focus=9.0))

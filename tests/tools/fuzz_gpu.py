@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised differential run of the HIP path against the CPU oracle (not collected by pytest):
-random scene kind, primitive order, candidate walk, resolution (odd sizes too), bounce count,
-termination probability, stack depth, sun option and frame range; every case must agree with the
-oracle in its primary hits, random-stream states, counters and image.
+"""Randomised differential run of the HIP path against the CPU oracle, as long as you like (the
+bounded, fixed-seed set that pytest collects is tests/test_gpu_fuzz.py; the cases come from
+tests/fuzz_cases.py): every case must agree with the oracle in its primary hits, random-stream
+states, counters, image and single rays.
     python tests/tools/fuzz_gpu.py [--cases 40] [--seed 1]"""
 import argparse
 import os
@@ -14,33 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 import torch  # noqa: F401,E402  (before the device library opens the GPU)
-from oracle import orc  # noqa: E402
-from raytracer_amd import device, procedural  # noqa: E402
-from util import oracle_params, oracle_scene, psnr, tonemapped  # noqa: E402
-
-
-def make_case(rng):
-    kind = rng.choice(["box", "materials", "terrain", "instanced", "instanced_shuffled", "atrium"])
-    walk = None
-    if kind == "box":
-        s = procedural.box_scene(env_size=(64, 32))
-    elif kind == "materials":
-        s = procedural.material_test_scene(tex=32, env_size=(64, 32))
-    elif kind == "terrain":
-        s = procedural.terrain_scene(tiles=int(rng.integers(1, 5)), n=int(rng.integers(6, 30)), env_size=(64, 32),
-                                     view=str(rng.choice(["ground", "top"])))
-    elif kind == "atrium":
-        s = procedural.atrium_scene(detail=0.02, tex=32, env_size=(64, 32))
-    else:
-        tiles = int(rng.integers(9, 40))
-        s = procedural.terrain_scene(tiles=tiles, n=int(rng.integers(4, 10)), env_size=(64, 32), instanced=True,
-                                     shuffled=kind.endswith("shuffled"), view=str(rng.choice(["ground", "top"])))
-        walk = str(rng.choice(["default", "scan", "pyramid", "list"]))
-    res = (int(rng.integers(1, 200)), int(rng.integers(1, 120)))
-    p = device.default_params(max_bounces=int(rng.integers(1, 9)), term_prob=float(rng.choice([0.5, 0.5, 0.25, 0.8])),
-                              stack_depth=int(rng.choice([1, 3, 8, 13, 14, 23, 23, 40, 64])), enable_sun=int(rng.integers(0, 2)))
-    first, n = int(rng.integers(1, 1000)), int(rng.integers(1, 4))
-    return kind, walk, s, res, p, first, n
+import fuzz_cases  # noqa: E402
 
 
 def main():
@@ -52,72 +26,11 @@ def main():
     rng = np.random.default_rng(args.seed)
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     bad = 0
-    for case in range(args.cases):
-        kind, walk, s, res, p, first, n = make_case(rng)
-        a = s.arrays()
-        for k in ("RTHIP_TREE_MIN_PRIMS", "RTHIP_CANDIDATE_WALK"):
-            os.environ.pop(k, None)
-        if walk == "pyramid":
-            os.environ["RTHIP_TREE_MIN_PRIMS"] = "8"
-        elif walk == "scan":
-            os.environ["RTHIP_TREE_MIN_PRIMS"] = "4000000000"
-        elif walk == "list":
-            os.environ["RTHIP_CANDIDATE_WALK"] = "list"
-        p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
-        u = s.frame_uniforms(res, frame=first, reject_hist=1)
-        c = device.Context(0)
-        try:
-            c.upload_scene(a)
-            got_walk = c.candidate_walk()
-            c.set_frame_uniforms(u)
-            c.reset_counters()
-            c.render(first, n, 1, p)
-            got = dict(accum=c.read_accum(), counters=c.counters(), **c.read_taps())
-            # single rays as well: random ones, and axis-parallel ones (zero direction components make the
-            # reciprocal infinite: the slab tests then run on infinities, shader.wgsl:415-438)
-            v = a["tris"]["v"][:, :, :3].reshape(-1, 3)
-            tr = np.asarray(a["prims"]["transform"], np.float32).reshape(-1, 16)[:, 12:15] # translations (column-major)
-            lo, hi = tr.min(0) + v.min(0) - 1.0, tr.max(0) + v.max(0) + 1.0
-            nq = args.rays
-            ro = rng.uniform(lo, hi, (nq, 3)).astype(np.float32)
-            rd = rng.normal(size=(nq, 3)).astype(np.float32)
-            rd /= np.linalg.norm(rd, axis=1, keepdims=True)
-            for k in range(0, nq, 3):
-                ax = int(rng.integers(0, 3))
-                rd[k] = 0.0
-                rd[k, ax] = float(rng.choice([-1.0, 1.0]))
-                if k % 2 == 0:
-                    ro[k] = np.round(ro[k])      # origins on round coordinates: on box faces and triangle planes of the procedural scenes
-            pq = device.default_params(stack_depth=p.stack_depth)
-            q = c.trace_rays(ro, rd, None, pq)
-        finally:
-            c.close()
-        sc_o = oracle_scene(a)
-        op_q = oracle_params(pq)
-        ray_bad = 0
-        for k in range(nq):
-            tri, prim, tt, _ = orc.trace_ray(sc_o, ro[k], rd[k], op_q, 0)
-            if q["tri"][k] != tri or (tri >= 0 and (q["prim"][k] != prim or q["t"][k] != np.float32(tt))):
-                ray_bad += 1
-        ref = orc.render(oracle_scene(a), u, oracle_params(p), first, n, 1, taps=True, n_threads=threads)
-        npx = res[0] * res[1]
-        tri_ok = float((got["tri"] == ref["tri"]).mean())
-        seed_ok = float((got["seed"] == ref["seed"]).mean())
-        same = got["seed"] == ref["seed"]
-        img_bad = int((~np.isclose(got["accum"], ref["accum"], rtol=2e-3, atol=2e-4).all(axis=-1) & same).sum())
-        alpha_ok = np.array_equal(got["accum"][..., 3], ref["accum"][..., 3])
-        cnt = {k: (got["counters"][k], ref["counters"][k]) for k in ("rays", "misses", "kills", "shade_calls", "stack_overflows", "shadow_rays")}
-        cnt_bad = [k for k, (g, r) in cnt.items() if abs(g - r) > max(4, 4e-3 * r)]
-        # Paths may part ways where an ulp of the device's sin / cos / pow decides a texel, a triangle edge or
-        # a comparison several bounces later (textured scenes, long paths): a few per thousand at most.
-        # The PSNR is printed for information: at 1-3 samples per pixel a handful of such pixels set it.
-        db = psnr(tonemapped(got["accum"]), tonemapped(ref["accum"]))
-        fail = ((1.0 - tri_ok) * npx > max(2, 1e-3 * npx) or (1.0 - seed_ok) * npx > max(3, 4e-3 * npx) or img_bad > max(3, 3e-3 * npx)
-                or not alpha_ok or cnt_bad or ray_bad)
-        bad += bool(fail)
-        print(f"{'FAIL' if fail else 'ok  '} case {case}: {kind} prims={a['prims'].shape[0]} walk={got_walk} res={res} bounces={p.max_bounces} "
-              f"p={p.term_prob} stack={p.stack_depth} sun={p.enable_sun} frames={first}+{n}: tri {tri_ok:.5f} seed {seed_ok:.5f} "
-              f"img_bad {img_bad} psnr {db:.1f} alpha {alpha_ok} counters {cnt_bad or 'ok'} rays_bad {ray_bad}", flush=True)
+    for i in range(args.cases):
+        case = fuzz_cases.make_case(rng)
+        fail, report, _ = fuzz_cases.run_case(case, rng, n_rays=args.rays, threads=threads)
+        bad += fail
+        print(f"{'FAIL' if fail else 'ok  '} case {i}: {report}", flush=True)
     print(f"{args.cases - bad} of {args.cases} cases agree")
     return 1 if bad else 0
 

@@ -55,22 +55,23 @@ def main():
     us = lambda t: round(float(t - t0) / 100.0, 1)   # 100 MHz ticks
     start, drain, end = rec[:, 0], rec[:, 1], rec[:, 2]
     trav, tail = rec[:, 3] & 0xFFFFFFFF, rec[:, 3] >> 32
-    lanes, unified, lanes_tail, heavy_ticks = rec[:, 4] & ((1 << 40) - 1), rec[:, 4] >> 40, rec[:, 5] & 0xFFFFFFFF, rec[:, 5] >> 32
+    lanes, shade_ticks, lanes_tail, heavy_ticks = rec[:, 4] & ((1 << 40) - 1), (rec[:, 4] >> 40) << 4, rec[:, 5] & 0xFFFFFFFF, rec[:, 5] >> 32
     shade, shade_lanes = rec[:, 6] & 0xFFFFFFFF, rec[:, 6] >> 32
-    scan, scan_lanes, refill = rec[:, 7] & 0xFFFFFFFF, (rec[:, 7] >> 32) & 0xFFFF, rec[:, 7] >> 48
+    scan, camera_ticks = rec[:, 7] & 0xFFFFFFFF, (rec[:, 7] >> 32) << 4
     print(json.dumps({
         "waves": int(rec.shape[0]), "span_us": us(end.max()), "last_wave_start_us": us(start.max()),
         "no_path_left_first_us": us(drain[drain > 0].min()), "no_path_left_median_us": us(np.median(drain[drain > 0])),
         "wave_end_us": {str(q): us(np.percentile(end, q)) for q in (10, 50, 90, 99, 100)},
-        "rounds_per_wave_median": {"traversal": int(np.median(trav)), "after_drain": int(np.median(tail)), "shade": int(np.median(shade)),
-                                   "scan": int(np.median(scan)), "refill": int(np.median(refill)), "unified": int(np.median(unified))},
-        "rounds_total": {"traversal": int(trav.sum()), "after_drain": int(tail.sum()), "shade": int(shade.sum()), "scan": int(scan.sum()), "refill": int(refill.sum())},
+        "rounds_per_wave_median": {"traversal": int(np.median(trav)), "after_drain": int(np.median(tail)), "path_rounds": int(np.median(shade)),
+                                   "mask_scans": int(np.median(scan))},
+        "rounds_total": {"traversal": int(trav.sum()), "after_drain": int(tail.sum()), "path_rounds": int(shade.sum()), "mask_scans": int(scan.sum())},
         "lanes_with_traversal_work_per_round": round(float(lanes.sum()) / max(int(trav.sum()), 1), 1),
         "the_same_after_the_drain": round(float(lanes_tail.sum()) / max(int(tail.sum()), 1), 1),
         "us_in_path_rounds_per_wave_median": round(float(np.median(heavy_ticks)) / 100.0, 1),
         "us_per_path_round": round(float(heavy_ticks.sum()) / 100.0 / max(int(shade.sum()), 1), 2),
-        "lanes_per_shade_round": round(float(shade_lanes.sum()) / max(int(shade.sum()), 1), 1),
-        "lanes_per_scan_round": round(float(scan_lanes.sum()) / max(int(scan.sum()), 1), 1),
+        "of_which_shading_us": round(float(shade_ticks.sum()) / 100.0 / max(int(shade.sum()), 1), 2),
+        "of_which_camera_paths_us": round(float(camera_ticks.sum()) / 100.0 / max(int(shade.sum()), 1), 2),
+        "lanes_shaded_per_path_round": round(float(shade_lanes.sum()) / max(int(shade.sum()), 1), 1),
         "us_per_round_before_drain_median": round(float(np.median((drain - start)[drain > 0] / 100.0 / np.maximum((trav - tail + shade)[drain > 0], 1))), 3),
         "us_per_round_after_drain_median": round(float(np.median((end - drain)[drain > 0] / 100.0 / np.maximum(tail[drain > 0], 1))), 3),
     }))
