@@ -57,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--enable-sun", action="store_true", help="the sun option (shadow rays); not the reference's live behaviour")
     ap.add_argument("--random-rays", type=int, default=0, help="also time this many uniformly random rays over the scene's extent through rthip_trace_rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-case", action="store_true", help="skip the HBM-bound side measurement (random rays over a tiled terrain that does not fit the caches)")
+    ap.add_argument("--hbm-tiles", type=int, default=48, help="the HBM case: terrain tiled this many times each way into one BVH (48: 18.8 M triangles, 1.5 GB of triangles and nodes)")
+    ap.add_argument("--hbm-rays", type=int, default=8_000_000)
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call latency measurement")
     ap.add_argument("--opaque", action="store_true", help="diagnostic: treat MASK/BLEND materials as opaque")
     ap.add_argument("--first-frame", type=int, default=1, help="frame index of the first timed step (RNG key)")
@@ -116,6 +119,17 @@ def extend_algorithmic_bytes(c):
     return (32 * (c["prims_visited"] + 2 * c["inner_steps"]) + 36 * c["tri_tests"] + 80 * c["prims_visited"])
 
 
+def extend_lane_loads(c):
+    """Vector loads the extend stage issues for the work counted in `c`, lane by lane: four per
+    inner-node step (the sibling pair's record), three per triangle test, six per primitive entered
+    (its record and the closest distance so far), three per ray fetched -- in 16-byte units: the
+    12-byte loads of a triangle's rows count three quarters, which is what the pipeline charges
+    them; and the wave-level loads that carried them (one per load of a step a wave executed)."""
+    lane = 4 * c["inner_steps"] + 3 * 0.75 * c["tri_tests"] + 6 * c["prims_visited"] + 3 * c["rays"]
+    wave = 4 * c["rounds_inner"] + 3 * 0.75 * c["rounds_leaf"] + 6 * c["rounds_prim"] + 3 * c["batches"]
+    return lane, wave
+
+
 def workload_key(args):
     """Name under which the hardware-counter figures of this workload are filed in profiles/pmc_per_ray.json."""
     if args.pmc_key:
@@ -170,6 +184,18 @@ def build_workload(args):
     return scene, name
 
 
+def granted_cores():
+    """Host threads this process may use: the box's own setting when it has one (OMP_NUM_THREADS),
+    else the CPUs in the process's affinity mask."""
+    n = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if n > 0:
+        return n
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
     """Times the CPU oracle (the build's own restatement, not the reference binary) on the first
     frames of the same workload, all host threads the box grants this process.  One untimed frame
@@ -180,7 +206,7 @@ def cpu_baseline(arrays, uniforms, params, target_seconds=12.0):
     sc = orc.make_scene(arrays["tris"], arrays["tri_exts"], arrays["nodes"], arrays["prims"],
                         arrays["texels"], env, env.shape[1], env.shape[0])
     op = orc.Params(params.max_bounces, params.term_prob, params.aperture_radius, params.stack_depth, params.enable_sun)
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = granted_cores()
     h = int(np.ascontiguousarray(uniforms).view(np.uint8).reshape(-1)[580:584].view(np.uint32)[0])
     t0 = time.perf_counter()
     orc.render(sc, uniforms, op, 1, 1, 1, n_threads=cores)   # one frame sizes the timed run
@@ -224,6 +250,36 @@ def random_rays_bench(ctx, arrays, n, params, device):
             "mrays_per_s": round(n / (ms * 1e-3) / 1e6, 1) if ms > 0 else None,
             "algorithmic_gbs": round(extend_algorithmic_bytes(c) / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
             "inner_steps_per_ray": round(c["inner_steps"] / n, 2), "tri_tests_per_ray": round(c["tri_tests"] / n, 2)}
+
+
+def hbm_case(ctx, args, device):
+    """The HBM-bound case of the same kernel, measured in the same run: uniformly random rays over a
+    tiled terrain merged into ONE BVH that is far larger than L2 + Infinity Cache.  Leaves the
+    terrain uploaded in ctx."""
+    from raytracer_amd import procedural
+    t0 = time.perf_counter()
+    scene = procedural.terrain_scene(tiles=args.hbm_tiles, n=args.terrain_n, view="top", env_size=(64, 32))
+    arrays = scene.arrays()
+    build_s = time.perf_counter() - t0
+    ctx.upload_scene(arrays)
+    p = device.default_params(stack_depth=48)
+    r = random_rays_bench(ctx, arrays, args.hbm_rays, p, device)
+    scene_bytes = int(arrays["tris"].nbytes + arrays["nodes"].nbytes)
+    key = f"terrain-t{args.hbm_tiles}-random-rays"
+    out = {"workload": f"terrain tiled {args.hbm_tiles}x{args.hbm_tiles} into one BVH, {args.hbm_rays} uniformly random rays (rthip_trace_rays), stack depth 48",
+           "triangles": int(arrays["tris"].shape[0]), "nodes": int(arrays["nodes"].shape[0]), "triangle_and_node_bytes": scene_bytes,
+           "host_build_s": round(build_s, 1), "rays": r["rays"], "extend_ms": r["extend_ms"], "mrays_per_s": r["mrays_per_s"],
+           "inner_steps_per_ray": r["inner_steps_per_ray"], "tri_tests_per_ray": r["tri_tests_per_ray"],
+           "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           # the algorithmic bytes of this launch over its duration, as a fraction of the HBM peak
+           "algorithmic_gbs": r["algorithmic_gbs"], "algorithmic_frac": round(r["algorithmic_gbs"] / HBM_PEAK_GBS, 4) if r["algorithmic_gbs"] else None,
+           "pmc_workload": key, "traffic_gbs": None, "traffic_frac": None}
+    pmc = pmc_figures(key)
+    if pmc and r["extend_ms"]:
+        gbs = (pmc["fetch_bytes_per_ray"] + pmc["write_bytes_per_ray"]) * r["rays"] / (r["extend_ms"] * 1e-3) / 1e9
+        out.update({"traffic_gbs": round(gbs, 1), "traffic_frac": round(gbs / HBM_PEAK_GBS, 4), "l2_hit_rate": pmc.get("l2_hit_rate"),
+                    "traffic_source": pmc["source"]})
+    return out
 
 
 def main():
@@ -301,8 +357,11 @@ def main():
         grp.synchronize()
         t0 = time.perf_counter()
         grp.render(args.first_frame, total_frames, p_plain)
+        grp.synchronize()
+        t_render = time.perf_counter() - t0
         grp.reduce(0)                                  # synchronous: every GPU's stream is drained
         elapsed = time.perf_counter() - t0
+        rank_ms = [[round(t_render * 1e3, 3), round((elapsed - t_render) * 1e3, 3)]] * world   # one process: the group's times
         timing = ctx.timing()
         for c in grp.contexts:
             c.reset_counters()
@@ -348,14 +407,22 @@ def main():
         t0 = time.perf_counter()
         ctx.render(first, count, world, p_plain)
         ctx.synchronize()
+        t_render = time.perf_counter() - t0
         if mode == "rank":
             dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        rank_ms = [[round(t_render * 1e3, 3), round((elapsed - t_render) * 1e3, 3)]]
         if mode == "rank":
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+            # what each rank spent rendering and (from the end of its own render to the end of the
+            # reduce, i.e. including the wait for the slowest rank) reducing
+            mine_ms = torch.tensor(rank_ms[0], dtype=torch.float64, device=f"cuda:{local_rank}")
+            all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+            dist.all_gather(all_ms, mine_ms)
+            rank_ms = [[round(float(v), 3) for v in t.tolist()] for t in all_ms]
         timing = ctx.timing()
 
         # identical frames again with counters on: the RNG is keyed by (pixel, frame), so the work
@@ -388,41 +455,69 @@ def main():
         algorithmic_gbs = (ext_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         key = workload_key(args)
         pmc = pmc_figures(key)
+        lane_loads, wave_loads = extend_lane_loads(counters)
+        active = max(1, min(64, int(round(lane_loads / max(wave_loads, 1)))))
+        ceiling = ctx.gather_ceiling(active)                 # lane-loads / s, measured now, on this GPU
+        lane_rate = (lane_loads / launches) / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         roof = {
-            # a byte-moving f32/integer kernel with no contraction: HBM is the roofline it is classed
-            # under.  `achieved` is the HBM-side traffic the hardware counters saw for this workload
-            # (per ray, from the committed rocprofv3 passes) x the rays of a launch / the launch time
-            # measured here with HIP events; `frac` is that over the vendor peak.
+            # A byte-moving f32 / integer kernel with no contraction: HBM is the roofline it is classed
+            # under.  `achieved` = the algorithmic bytes of a launch (the counting rule of
+            # extend_algorithmic_bytes on this run's own traversal counters) / the launch's duration,
+            # measured here with HIP events on the library's stream; `frac` = achieved / the HBM peak.
+            # Where the working set lives in L1 / L2 / Infinity Cache that fraction EXCEEDS 1 (the
+            # caches deliver the bytes, HBM does not have to): HBM is then not what binds, `binding`
+            # below names what does, and `hbm_case` is the same kernel where HBM does bind.
             "bound": "hbm",
             "kernel": "k_extend",
-            "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "achieved": round(algorithmic_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
+            "frac_note": ("above 1: the scene's %.0f MB of nodes and triangles are served by the caches; see binding and hbm_case"
+                          % ((arrays["tris"].nbytes + 2 * arrays["nodes"].nbytes) / 1e6)) if algorithmic_gbs > HBM_PEAK_GBS else None,
+            "traffic": None,
             "peak_stream_copy": round(copy_gbs, 1),
             "launches": ext["launches"],
             "avg_launch_ms": round(avg_ms, 5),
             "rays_per_launch": round(rays_per_launch, 1),
-            # what the caches deliver: the bytes the traversal needs by the counting rule above over
-            # the same time.  A delivery rate of L1 + L2 + Infinity Cache + HBM together, not a
-            # fraction of any one peak.
             "algorithmic_bytes_per_launch": round(ext_bytes / launches, 1),
             "algorithmic_gbs": round(algorithmic_gbs, 2),
             "pmc_workload": key,
+            # The ceiling that binds when the scene is cache-resident: the CU's vector-memory pipeline
+            # (address unit, L1 tag look-up, data return).  Unit = lane-loads: one lane's 16-byte load
+            # (a 12-byte load counts 3/4).  achieved = the loads the traversal counters imply (4 per inner
+            # step, 3 x 3/4 per triangle test, 6 per primitive entered, 3 per ray fetched) per second of k_extend;
+            # ceiling = rthip_gather_ceiling at the same number of active lanes per wave-level load:
+            # the same access shape from an L1-resident table, no dependence between steps.
+            "binding": {
+                "resource": "CU vector-memory pipeline: lane-loads of the divergent record fetches (address unit, L1 look-up, data return)",
+                "unit": "Glane-loads/s (16-byte loads)",
+                "achieved": round(lane_rate / 1e9, 1),
+                "ceiling": round(ceiling / 1e9, 1),
+                "frac": round(lane_rate / ceiling, 4) if ceiling > 0 else None,
+                "active_lanes_per_wave_load": active,
+                "lane_loads_per_ray": round(lane_loads / max(rays_local, 1), 1),
+                "ceiling_source": "rthip_gather_ceiling, this run, this GPU: 64-byte records out of the L1, 8 waves per SIMD, independent steps",
+            },
         }
         if pmc and avg_ms > 0:
-            hbm_bytes = (pmc["fetch_bytes_per_ray"] + pmc["write_bytes_per_ray"]) * rays_per_launch
-            hbm_gbs = hbm_bytes / (avg_ms * 1e-3) / 1e9
+            fabric_bytes = (pmc["fetch_bytes_per_ray"] + pmc["write_bytes_per_ray"]) * rays_per_launch
+            fabric_gbs = fabric_bytes / (avg_ms * 1e-3) / 1e9
             l2_gbs = pmc["l2_read_bytes_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / 1e9
             roof.update({
-                "achieved": round(hbm_gbs, 1),
-                "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
-                "frac_of_stream_copy": round(hbm_gbs / copy_gbs, 4) if copy_gbs > 0 else None,
-                "traffic": round(hbm_bytes, 1),
-                "traffic_over_algorithmic": round(hbm_bytes / max(ext_bytes / launches, 1.0), 4),
+                # what left the L2s towards Infinity Cache + HBM per launch, from the hardware counters
+                # (FETCH_SIZE x 2 on gfx950, + WRITE_SIZE; separate rocprofv3 --pmc passes of this
+                # command, per ray, scaled by this run's rays).  FETCH_SIZE counts requests that the
+                # Infinity Cache then serves as well: an upper bound of the HBM bytes.
+                "traffic": round(fabric_bytes, 1),
+                "fabric_traffic_gbs": round(fabric_gbs, 1),
+                "fabric_traffic_frac": round(fabric_gbs / HBM_PEAK_GBS, 4),
+                "fabric_traffic_frac_of_stream_copy": round(fabric_gbs / copy_gbs, 4) if copy_gbs > 0 else None,
+                "traffic_over_algorithmic": round(fabric_bytes / max(ext_bytes / launches, 1.0), 4),
                 "traffic_source": pmc["source"],
+                "traffic_profiled_at": pmc.get("bench_args"),
                 "l2_hit_rate": pmc.get("l2_hit_rate"),
                 "l2_to_l1_gbs": round(l2_gbs, 1),
                 "l2_frac": round(l2_gbs / L2_PEAK_GBS, 4),
-                # what the stage is measured to be limited by: busy fractions of the CU's
-                # vector-memory units (address unit TA, data-return unit TD) over the dispatch
+                # busy (non-idle) fractions of the CU's vector-memory units over the dispatch
                 "measured_limiter": {"unit": pmc.get("limiter_unit"), "busy_frac": pmc.get("limiter_busy_frac"),
                                      "address_unit_busy": pmc.get("ta_busy"), "data_return_busy": pmc.get("td_busy"),
                                      "data_return_stalled_on_l1_miss": pmc.get("td_tc_stall"),
@@ -465,6 +560,9 @@ def main():
                 "candidate_walk": ctx.candidate_walk(),
             },
             "rays_per_step_per_gpu": round(rays_local / local_frames, 1),
+            # per rank: milliseconds in its own render, and from the end of that to the end of the reduce
+            "render_ms_per_rank": [r[0] for r in rank_ms],
+            "reduce_ms_per_rank": [r[1] for r in rank_ms],
             "stage_ms_per_step": {s: round(timing[s]["ms"] / local_frames, 4) for s in ("generate", "cull", "extend", "shade", "shadow", "accumulate")},
             "roofline": roof,
             "counters_per_ray": {k: round(counters[k] / max(rays_local, 1), 3)
@@ -497,6 +595,8 @@ def main():
             out["random_rays"] = random_rays_bench(ctx, arrays, args.random_rays, p_plain, device)
         if mode == "single" and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arrays, uniforms, p_plain)
+        if mode == "single" and not args.no_hbm_case:
+            out["roofline"]["hbm_case"] = hbm_case(ctx, args, device)   # last: it replaces the scene in ctx
         print(json.dumps(out), flush=True)
 
     if grp is not None:

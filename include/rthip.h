@@ -214,8 +214,12 @@ int rthip_trace_rays(rthip_ctx* ctx, const float* rays6, uint32_t* seeds, uint64
  * ALL pointers are DEVICE memory of the context's GPU (caller-owned): d_rays6 as rays6 above,
  * d_seeds (may be NULL) read and advanced in place, outputs as above (any may be NULL).
  * Asynchronous: the work is enqueued on the context's stream and nothing is synchronised.
- * Every call on a GPU, from any context, uses that GPU's one array: calls that overlap in time on
- * one GPU (two contexts, two streams) race; calls on one stream are ordered and safe. */
+ * Every call on a GPU, from any context, uses that GPU's one array.  The library orders them: a call
+ * waits, on its stream, for the previous call on that GPU (one event per GPU, created with the first
+ * context on it; no allocation per call), so two contexts or two streams may issue calls freely.
+ * The exception is a stream under graph capture, where the event is not used: calls captured into
+ * graphs that may run at the same time on one GPU race on the array, and keeping them apart is the
+ * caller's business. */
 #define RTHIP_NOALLOC_MAX_RAYS (1u << 18)
 int rthip_trace_rays_noalloc(rthip_ctx* ctx, const float* d_rays6, uint32_t* d_seeds, uint64_t n,
                              const rthip_render_params* params, float* d_t, int32_t* d_tri_idx,
@@ -235,6 +239,15 @@ int rthip_reset_timing(rthip_ctx* ctx);
  * stream and returns the achieved HBM traffic in GB/s (bytes read + bytes written per second), the
  * stream-copy ceiling that bandwidth fractions can be quoted against.  No counterpart upstream. */
 int rthip_copy_bandwidth(rthip_ctx* ctx, uint64_t bytes, uint32_t repeats, double* gb_per_s);
+
+/* Measurement aid: the rate at which the GPU's vector-memory pipelines serve the access shape of the
+ * traversal when memory latency is out of the picture -- `active_lanes` scattered lanes of every
+ * wave (1..64) each read the four 16-byte pieces of a 64-byte record of their own per step, as an
+ * inner-node step of trace_bvh (shader.wgsl:496-521) does, from a table that stays in the L1, eight
+ * waves per SIMD, no dependence between steps.  Returns lane-loads (16 bytes each) per second over
+ * the whole chip: the ceiling that the extend stage's own lane-loads per second are quoted against
+ * on scenes that live in the caches, where HBM bandwidth does not bind.  No counterpart upstream. */
+int rthip_gather_ceiling(rthip_ctx* ctx, uint32_t active_lanes, double* lane_loads_per_s);
 
 int rthip_synchronize(rthip_ctx* ctx);
 

@@ -661,6 +661,7 @@ static int trace_shadow(Ctx* cx, const Ray* ray) {
                     uint32_t far_child = left < right ? node.first + 1 : node.first;
                     uint32_t near_child = left < right ? node.first : node.first + 1;
                     if (sp < depth) stack[sp++] = far_child;
+                    else cx->debug = -99999999.0f; /* push() -> assert(false), shader.wgsl:306-313: the pixel turns yellow (:941-943) */
                     node = s->nodes[near_child];
                 }
             }

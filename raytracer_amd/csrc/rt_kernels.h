@@ -1546,11 +1546,14 @@ __global__ __launch_bounds__(256) void k_shadow_resolve(ShadowArgs a) {
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
         const float4 s1 = a.in.s1[slot], s2 = a.in.s2[slot], s3 = a.in.s3[slot];
         const uint32_t pix = __float_as_uint(s1.w);
-        const bool occluded = __float_as_int(a.hits[slot].y) >= 0;
+        const float4 h = a.hits[slot];
+        const bool occluded = __float_as_int(h.y) >= 0;
         c_shadow++;
         f3 lit = F3(s3.x, s3.y, s3.z);
         if (!occluded) lit = lit + F3(s2.x, s2.y, s2.z);
-        if (s2.w != 0.0f) lit = F3(1.0f, 1.0f, 0.0f); // a dropped push on the camera path, shader.wgsl:941-943
+        // a dropped push in the path's last trace() or in trace_bvh_shadow itself (push() -> assert,
+        // shader.wgsl:306-313): the pixel turns yellow (:941-943)
+        if (s2.w != 0.0f || (__float_as_uint(h.z) >> 31) != 0u) lit = F3(1.0f, 1.0f, 0.0f);
         a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
         if (a.tap_seed && pix < a.n_pixels) a.tap_seed[pix] = __float_as_uint(s1.z);
     }
@@ -1643,4 +1646,28 @@ __global__ __launch_bounds__(256) void k_unpack_hits(const float4* hits, uint32_
     if (prim_idx) prim_idx[i] = tri >= 0 ? (int32_t)(primw & 0x7FFFFFFFu) : -1;
     if (overflow) overflow[i] = (uint8_t)(primw >> 31);
     if (seeds) seeds[i] = __float_as_uint(h.w);
+}
+
+// ------------------------------------------------------------------ measurement aid: the gather ceiling
+
+// What a CU's vector-memory pipeline sustains for the access shape of the extend stage when memory
+// latency is out of the picture: every ACTIVE lane of a wave (lanes chosen by `mask`) reads the four
+// 16-byte pieces of a 64-byte record of its own per iteration -- the shape of an inner-node step --
+// from a 16 KiB table that stays in the L1; the loads of an iteration do not depend on each other
+// and eight waves share a SIMD, so the time is the throughput of the address / tag / return path,
+// not a latency.  The record a lane reads changes every iteration (a small LCG), as the nodes of a
+// traversal do.
+__global__ __launch_bounds__(256, 8) void k_gather_ceiling(const float4* table, unsigned long long mask, uint32_t iters, float* sink) {
+    const uint32_t lane = lane_id();
+    float acc = 0.0f;
+    if ((mask >> lane) & 1ull) {
+        uint32_t idx = (threadIdx.x * 7u + blockIdx.x * 13u) & 255u; // 256 records of 64 bytes
+        for (uint32_t i = 0; i < iters; i++) {
+            const float4* r = table + idx * 4u;
+            const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+            acc += (a.x + b.y) + (c.z + d.w);
+            idx = (idx * 5u + 1u) & 255u;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc; // never true: keeps the loads
 }

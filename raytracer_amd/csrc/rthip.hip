@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,13 @@
 #define RT_NOALLOC_SPILL_WORDS ((size_t)(RT_MAX_STACK - RT_LDS_LEVELS_SINGLE) * RT_NOALLOC_DEEP_GRID * 256u)
 #define RT_NOALLOC_BYTES      (RT_NOALLOC_SPILL_OFF + 4 * RT_NOALLOC_SPILL_WORDS)
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+// Every call of rthip_trace_rays_noalloc on a GPU uses that GPU's one array, whatever context or
+// stream it comes from.  One event per GPU, created with the first context on it and kept until the
+// process ends, orders them: a call waits on the event before its first kernel and records it
+// after its last, and a host mutex makes "wait, enqueue, record" one step.
+#define RT_MAX_DEVICES 64
+static hipEvent_t g_noalloc_done[RT_MAX_DEVICES];
+static std::mutex g_noalloc_mutex[RT_MAX_DEVICES];
 
 namespace {
 
@@ -54,6 +62,7 @@ struct rthip_ctx {
     hipStream_t stream = nullptr;
     int         n_cu = 0;
     std::string error;
+    bool        tuning = false;  // RTHIP_TUNING was set when the context was made: the RTHIP_* experiment knobs are honoured
 
     // scene
     bool      have_scene = false;
@@ -149,6 +158,12 @@ int fail(rthip_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+// The RTHIP_* environment knobs (candidate walk, frames in flight, grid sizes ...) exist for
+// experiments and tests.  They are looked at only by contexts created while RTHIP_TUNING was set to
+// a non-zero value: a stray variable in a production environment changes nothing, and a render
+// reads no environment at all.
+const char* knob(const rthip_ctx* c, const char* name) { return c->tuning ? std::getenv(name) : nullptr; }
+
 #define HIP_TRY(ctx, expr)                                                                      \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -233,7 +248,7 @@ bool invert4(const double m[16], double out[16]) {
 // path).  RTHIP_FRAMES_IN_FLIGHT overrides the default.
 uint32_t frames_in_flight_limit(const rthip_ctx* c) {
     uint32_t want = 64;
-    if (const char* e = std::getenv("RTHIP_FRAMES_IN_FLIGHT")) {
+    if (const char* e = knob(c, "RTHIP_FRAMES_IN_FLIGHT")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 128) want = (uint32_t)v;
     }
@@ -433,6 +448,7 @@ int rthip_create(int device_ordinal, rthip_ctx** out) {
     rthip_ctx* c = new rthip_ctx();
     c->device = device_ordinal;
     c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("RTHIP_TUNING")) c->tuning = std::atoi(e) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, RTHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
@@ -452,6 +468,13 @@ int rthip_create(int device_ordinal, rthip_ctx** out) {
     // every GPU holds its own copy of the static work array at its own address
     e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !c->noalloc_scratch) { rthip_destroy(c); return fail(nullptr, RTHIP_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
+    if (device_ordinal < RT_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_noalloc_mutex[device_ordinal]);
+        if (!g_noalloc_done[device_ordinal] && hipEventCreateWithFlags(&g_noalloc_done[device_ordinal], hipEventDisableTiming) != hipSuccess) {
+            g_noalloc_done[device_ordinal] = nullptr; // without it overlapping calls race, as documented
+            (void)hipGetLastError();
+        }
+    }
     *out = c;
     return RTHIP_OK;
 }
@@ -735,8 +758,9 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     // estimate is made for every scene of more than 128 primitives: it also decides between the scan
     // and the per-ray candidate lists below.
     uint32_t tree_min = 511u;
-    const bool tree_min_forced = std::getenv("RTHIP_TREE_MIN_PRIMS") != nullptr; // tuning / test knob: pyramid above, scan up to it
-    if (tree_min_forced) tree_min = (uint32_t)std::strtoul(std::getenv("RTHIP_TREE_MIN_PRIMS"), nullptr, 10);
+    const char* tree_min_env = knob(c, "RTHIP_TREE_MIN_PRIMS"); // tuning / test knob: pyramid above, scan up to it
+    const bool tree_min_forced = tree_min_env != nullptr;
+    if (tree_min_forced) tree_min = (uint32_t)std::strtoul(tree_min_env, nullptr, 10);
     const bool pyramid_possible = s->n_prims > 8u && (uint64_t)s->n_prims <= (1ull << (3u * RT_TLAS_MAX_LEVELS));
     bool tree = s->n_prims > tree_min && pyramid_possible;
     bool coherent = true;
@@ -792,12 +816,12 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     // it; such a scene keeps the scan.
     // (shuffled instances, scan against lists: 288 primitives 2.6 against 3.3 Grays/s, 512: 1.5 against 3.2.)
     bool lists = !tree && !coherent && s->n_prims > 128u && !tree_min_forced;
-    if (const char* e = std::getenv("RTHIP_CANDIDATE_WALK")) { // test / tuning knob: scan, pyramid or list for any scene of more than 128 primitives
+    if (const char* e = knob(c, "RTHIP_CANDIDATE_WALK")) { // test / tuning knob: scan, pyramid or list for any scene of more than 128 primitives
         const std::string want(e);
         if (s->n_prims > 128u && (want == "scan" || want == "pyramid" || want == "list")) {
             lists = want == "list";
-            if (want == "pyramid" && tlas.empty()) return fail(c, RTHIP_ERR_INVALID, "upload_scene: RTHIP_CANDIDATE_WALK=pyramid needs RTHIP_TREE_MIN_PRIMS below the primitive count");
-            tree = want == "pyramid";
+            // no pyramid was built (more than 8^RT_TLAS_MAX_LEVELS primitives, or a bound that is not finite): such a scene keeps the scan
+            tree = want == "pyramid" && !tlas.empty();
         }
     }
     uint32_t ptree_depth = 0; // inner levels: 4^depth >= primitives
@@ -883,7 +907,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
         // longer lists pay where rays cross many bounds (8192 shuffled instances: 1476 -> 1777 Mrays/s)
         // and cost where they do not (2048: 2669 -> 2623): the cull kernel's LDS and the bytes double
         c->list_len = s->n_prims >= 4096u ? RT_LIST_LEN_LONG : RT_LIST_LEN;
-        if (const char* e = std::getenv("RTHIP_LIST_LEN")) { // tuning / test knob
+        if (const char* e = knob(c, "RTHIP_LIST_LEN")) { // tuning / test knob
             const int v = std::atoi(e);
             if (v == (int)RT_LIST_LEN || v == (int)RT_LIST_LEN_LONG) c->list_len = (uint32_t)v;
         }
@@ -1036,9 +1060,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     // the extend stage: 4.8 -> 4.2 ms for one 1080p frame of the atrium).  Longer calls keep whole
     // tiles, which is worth 14 % of their throughput.  RTHIP_SPREAD (0, 2, 4) overrides for experiments.
     int spread_env = -1;
-    if (const char* e = std::getenv("RTHIP_SPREAD")) spread_env = std::atoi(e);
+    if (const char* e = knob(c, "RTHIP_SPREAD")) spread_env = std::atoi(e);
     int path_blocks_env = 0;
-    if (const char* e = std::getenv("RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
+    if (const char* e = knob(c, "RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
     const bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
 
     PathQueue q[2];
@@ -1055,10 +1079,10 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     // with a handful of primitives the candidate test saves less than it costs
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     bool cull_camera = true;
-    if (const char* e = std::getenv("RTHIP_CULL_CAMERA")) cull_camera = std::atoi(e) != 0; // diagnostic: 0 = the general cull kernel for camera rays too
+    if (const char* e = knob(c, "RTHIP_CULL_CAMERA")) cull_camera = std::atoi(e) != 0; // diagnostic: 0 = the general cull kernel for camera rays too
     int ext_blocks = extend_occupancy(count, deep, ext_mode);
     bool ext_blocks_fixed = false;
-    if (const char* e = std::getenv("RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
+    if (const char* e = knob(c, "RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
         const int v = std::atoi(e);
         if (v > 0 && v <= 16) { ext_blocks = v; ext_blocks_fixed = true; }
     }
@@ -1508,6 +1532,18 @@ int rthip_trace_rays_noalloc(rthip_ctx* c, const float* d_rays6, uint32_t* d_see
     if (deep) grid = std::min<uint32_t>(grid, RT_NOALLOC_DEEP_GRID); // the deep stack columns are a fixed part of the work array
     (void)hipGetLastError(); // not this call's
 
+    // Order this call behind the last one that used the GPU's work array (another context, another
+    // stream).  Not while the stream is being captured into a graph: an event recorded outside the
+    // capture cannot be waited on inside it, and the order of a graph's nodes is the caller's.
+    hipEvent_t order = c->device < RT_MAX_DEVICES ? g_noalloc_done[c->device] : nullptr;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &capture) != hipSuccess) { capture = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+    if (capture != hipStreamCaptureStatusNone) order = nullptr;
+    std::unique_lock<std::mutex> lock;
+    if (order) {
+        lock = std::unique_lock<std::mutex>(g_noalloc_mutex[c->device]);
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, order, 0));
+    }
     const uint32_t flat_grid = (nn + 255u) / 256u;
     hipLaunchKernelGGL(k_pack_rays, dim3(flat_grid), dim3(256), 0, c->stream, d_rays6, (const uint32_t*)d_seeds, nn, planes, planes + RT_NOALLOC_MAX_RAYS, ctl);
     ExtArgs ea{};
@@ -1534,6 +1570,7 @@ int rthip_trace_rays_noalloc(rthip_ctx* c, const float* d_rays6, uint32_t* d_see
     }
     extend_launch(count, deep, ext_mode, grid, c->stream, ea);
     hipLaunchKernelGGL(k_unpack_hits, dim3(flat_grid), dim3(256), 0, c->stream, (const float4*)hits, nn, d_t, d_tri_idx, d_prim_idx, d_overflow, d_seeds);
+    if (order) HIP_TRY(c, hipEventRecord(order, c->stream));
     HIP_TRY(c, hipGetLastError());
     return RTHIP_OK;
 }
@@ -1735,6 +1772,45 @@ int rthip_copy_bandwidth(rthip_ctx* c, uint64_t bytes, uint32_t repeats, double*
     if (b) (void)hipFree(b);
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "copy_bandwidth: %s", hipGetErrorString(e));
     *gb_per_s = ms > 0.0f ? 2.0 * (double)bytes * repeats / ((double)ms * 1e-3) / 1e9 : 0.0;
+    return RTHIP_OK;
+}
+
+int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, double* lane_loads_per_s) {
+    if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
+    if (!lane_loads_per_s || active_lanes == 0 || active_lanes > 64) return fail(c, RTHIP_ERR_INVALID, "gather_ceiling: null result, or active_lanes outside 1..64");
+    DeviceGuard g(c->device);
+    // `active_lanes` lanes spread over the wave by a fixed permutation (scattered, as the lanes that
+    // share a step kind are)
+    unsigned long long mask = 0ull;
+    for (uint32_t k = 0, lane = 5u; k < active_lanes; k++, lane = (lane + 37u) & 63u) mask |= 1ull << lane; // 37 is odd: a permutation of 0..63
+    const uint32_t iters = 2000u, blocks = (uint32_t)c->n_cu * 8u;
+    void* table = nullptr;
+    float* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&table, 256 * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&sink, sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(table, 0, 256 * 64, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_ceiling, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, 50u, sink); // untimed: code and table in the caches
+        e = hipEventRecord(e0, c->stream);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_ceiling, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, iters, sink);
+        e = hipEventRecord(e1, c->stream);
+    }
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (table) (void)hipFree(table);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "gather_ceiling: %s", hipGetErrorString(e));
+    // blocks x 4 waves x iters iterations x 4 loads, each by active_lanes lanes
+    *lane_loads_per_s = ms > 0.0f ? (double)blocks * 4.0 * iters * 4.0 * active_lanes / ((double)ms * 1e-3) : 0.0;
     return RTHIP_OK;
 }
 

@@ -26,7 +26,7 @@ EXPORTS = (
     "rthip_read_tri_order", "rthip_read_tris_device_layout", "rthip_resolve",
     "rthip_get_counters", "rthip_reset_counters", "rthip_get_timing", "rthip_reset_timing",
     "rthip_synchronize", "rthip_copy_bandwidth", "rthip_trace_rays", "rthip_trace_rays_noalloc",
-    "rthip_frames_in_flight", "rthip_candidate_walk",
+    "rthip_frames_in_flight", "rthip_candidate_walk", "rthip_gather_ceiling",
 )
 
 
@@ -94,6 +94,7 @@ def lib():
         l.rthip_trace_rays.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_trace_rays_noalloc.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_copy_bandwidth.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+        l.rthip_gather_ceiling.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
         l.rthip_default_params.restype = None
         l.rthip_render.argtypes = [vp, u32, u32, u32, C.POINTER(RenderParams)]
         l.rthip_bind_accum.argtypes = [vp, vp, u64]
@@ -239,6 +240,13 @@ class Context:
         """Device-to-device stream-copy ceiling in GB/s (read + write traffic)."""
         out = C.c_double()
         self._check(lib().rthip_copy_bandwidth(self._h, int(nbytes), int(repeats), C.byref(out)))
+        return float(out.value)
+
+    def gather_ceiling(self, active_lanes):
+        """Lane-loads (16 bytes each) per second that the chip's vector-memory pipelines serve for the
+        inner-node access shape from the L1, `active_lanes` scattered lanes per wave."""
+        out = C.c_double()
+        self._check(lib().rthip_gather_ceiling(self._h, int(active_lanes), C.byref(out)))
         return float(out.value)
 
     def synchronize(self):

@@ -41,15 +41,19 @@ class DeviceRenderer:
         self.accum = torch.zeros(res[0] * res[1] * 4, dtype=torch.float32, device=device)
         ctx.bind_accum(self.accum.data_ptr(), res[0] * res[1])
 
-    def render(self, scene, total_frames, rank, world, params=None, first_frame=1, dist=None):
+    def render(self, scene, total_frames, rank, world, params=None, first_frame=1, dist=None, root=0, reduce_fn=None):
+        """Renders this rank's stripe and sums the accumulators into rank `root`.  `dist` =
+        torch.distributed with an initialised group whose backend reduces device tensors in place
+        (RCCL: "nccl"); or pass reduce_fn(tensor) for another way of summing (e.g. an all-reduce
+        through a backend that has no device-side reduce)."""
         self.ctx.set_frame_uniforms(scene.frame_uniforms(self.res, frame=first_frame, reject_hist=1))
 
         def render_fn(first, count, stride):
             self.ctx.render(first, count, stride, params)
             self.ctx.synchronize()
 
-        def reduce_fn(t):
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        if reduce_fn is None and dist is not None:
+            def reduce_fn(t):
+                dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
 
-        return render_striped(render_fn, self.accum, total_frames, rank, world, first_frame,
-                              reduce_fn if dist is not None else None)
+        return render_striped(render_fn, self.accum, total_frames, rank, world, first_frame, reduce_fn)

@@ -15,6 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 REFERENCE_RESOURCES = "/root/reference/resources"
 
+# The device library honours its RTHIP_* experiment knobs (forced candidate walks, frames in flight,
+# ...) only in contexts created while RTHIP_TUNING is set; several tests force a walk that way.
+os.environ["RTHIP_TUNING"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -210,6 +210,28 @@ def test_sun_option_matches_oracle(ctx, scenes, name, res):
     assert float(got["accum"][..., :3].sum()) > float(dark["accum"][..., :3].sum()) * 1.02
 
 
+def test_sun_shadow_ray_with_a_dropped_push_paints_the_pixel(ctx, scenes):
+    """trace_bvh_shadow pushes through the same 23-entry stack (shader.wgsl:528-575): a push it has to
+    drop sets `debug` like any other (306-313), and the pixel ends yellow (941-943), also when the
+    camera path's own traversal dropped nothing.  A stack of one entry makes that common."""
+    s, a = scenes["terrain"]
+    p = device.default_params(max_bounces=2, stack_depth=1)
+    p.enable_sun = 1
+    got, ref = run_both(ctx, s, a, (96, 64), n_frames=1, params=p)
+    same = got["seed"] == ref["seed"]
+    assert float(same.mean()) >= 0.995
+    yellow_ref = (ref["accum"][..., 0] == 1.0) & (ref["accum"][..., 1] == 1.0) & (ref["accum"][..., 2] == 0.0)
+    yellow_got = (got["accum"][..., 0] == 1.0) & (got["accum"][..., 1] == 1.0) & (got["accum"][..., 2] == 0.0)
+    assert yellow_ref.any()
+    assert np.array_equal(yellow_got[same], yellow_ref[same])
+    np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
+    # some of those pixels are yellow ONLY because of the shadow ray: without the sun they are not
+    p.enable_sun = 0
+    _, ref_dark = run_both(ctx, s, a, (96, 64), n_frames=1, params=p)
+    yellow_dark = (ref_dark["accum"][..., 0] == 1.0) & (ref_dark["accum"][..., 1] == 1.0) & (ref_dark["accum"][..., 2] == 0.0)
+    assert (yellow_ref & ~yellow_dark).any()
+
+
 def test_errors_are_reported_not_thrown(scenes):
     c = device.Context(0)
     with pytest.raises(device.RtHipError) as e:

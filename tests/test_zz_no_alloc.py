@@ -84,3 +84,73 @@ def test_noalloc_rejects_more_rays_than_its_work_array_holds():
             ctx.trace_rays_noalloc(16, 0, device.NOALLOC_MAX_RAYS + 1, 0, 0, 0, 0)
     finally:
         ctx.close()
+
+
+def test_noalloc_allocates_nothing_on_its_very_first_call():
+    """A fresh context, a stack deeper than the LDS levels (the deep columns and the host-side walk
+    for NaN rays are first used here), and the entry point called BEFORE rthip_trace_rays ever ran:
+    the device's free memory is the same before and after, and the result still equals rthip_trace_rays'."""
+    import torch
+    s = procedural.terrain_scene(tiles=4, env_size=(64, 32))
+    a = s.arrays()
+    params = device.default_params(stack_depth=40)
+    o, d, seeds = rays_for(a, 20000, 5)
+    d[:8] = np.nan                      # NaN directions take the precomputed walk
+    ctx = device.Context(0)
+    try:
+        ctx.upload_scene(a)
+        dev = "cuda:0"
+        rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([o, d], axis=1))).to(dev)
+        sd = torch.from_numpy(seeds.view(np.int32).copy()).to(dev)
+        n = o.shape[0]
+        t = torch.zeros(n, dtype=torch.float32, device=dev)
+        tri = torch.zeros(n, dtype=torch.int32, device=dev)
+        prim = torch.zeros(n, dtype=torch.int32, device=dev)
+        ovf = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        ctx.trace_rays_noalloc(rays.data_ptr(), sd.data_ptr(), n, t.data_ptr(), tri.data_ptr(), prim.data_ptr(), ovf.data_ptr(), params)
+        ctx.synchronize()
+        free_after = torch.cuda.mem_get_info(0)[0]
+        assert free_after == free_before, (free_before, free_after)
+        ref = ctx.trace_rays(o, d, seeds, params)
+        assert np.array_equal(tri.cpu().numpy(), ref["tri"]) and t.cpu().numpy().tobytes() == ref["t"].tobytes()
+        assert np.all(ref["tri"][:8] == -1)
+    finally:
+        ctx.close()
+
+
+def test_noalloc_calls_of_two_contexts_on_two_streams_do_not_mix():
+    """Both contexts share the GPU's one work array; the library orders their calls (one event per
+    GPU), so interleaved calls on different streams each get their own result."""
+    import torch
+    s = procedural.material_test_scene(tex=32, env_size=(64, 32))
+    a = s.arrays()
+    params = device.default_params()
+    c1, c2 = device.Context(0), device.Context(0)
+    try:
+        for c in (c1, c2):
+            c.upload_scene(a)
+        sets = [rays_for(a, 60000 + 7000 * k, 10 + k) for k in range(6)]
+        refs = [c1.trace_rays(o, d, sd, params) for o, d, sd in sets]
+        dev = "cuda:0"
+        bufs = []
+        for o, d, sd in sets:
+            n = o.shape[0]
+            bufs.append(dict(rays=torch.from_numpy(np.ascontiguousarray(np.concatenate([o, d], axis=1))).to(dev),
+                             sd=torch.from_numpy(sd.view(np.int32).copy()).to(dev),
+                             t=torch.zeros(n, dtype=torch.float32, device=dev), tri=torch.zeros(n, dtype=torch.int32, device=dev),
+                             prim=torch.zeros(n, dtype=torch.int32, device=dev), ovf=torch.zeros(n, dtype=torch.uint8, device=dev), n=n))
+        torch.cuda.synchronize()
+        for k, b in enumerate(bufs):     # alternate the contexts (each has a stream of its own), no host synchronisation in between
+            c = (c1, c2)[k % 2]
+            c.trace_rays_noalloc(b["rays"].data_ptr(), b["sd"].data_ptr(), b["n"], b["t"].data_ptr(), b["tri"].data_ptr(), b["prim"].data_ptr(), b["ovf"].data_ptr(), params)
+        c1.synchronize()
+        c2.synchronize()
+        for b, ref in zip(bufs, refs):
+            assert np.array_equal(b["tri"].cpu().numpy(), ref["tri"])
+            assert b["t"].cpu().numpy().tobytes() == ref["t"].tobytes()
+            assert np.array_equal(b["sd"].cpu().numpy().view(np.uint32), ref["seed"])
+    finally:
+        c1.close()
+        c2.close()

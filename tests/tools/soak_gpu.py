@@ -10,6 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+os.environ["RTHIP_TUNING"] = "1"   # the forced candidate walks are experiment knobs
 import torch  # noqa: E402  (before the device library opens the GPU)
 from raytracer_amd import device, procedural  # noqa: E402
 

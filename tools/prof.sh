@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 STEPS=${PROF_STEPS:-64}
-ARGS="--steps $STEPS --warmup $STEPS --no-cpu-baseline --no-single-frame $*"
+ARGS="--steps $STEPS --warmup ${PROF_WARMUP:-$STEPS} --no-cpu-baseline --no-single-frame --no-hbm-case $*"
 LIMIT=${PROF_LIMIT:-240}
 CMD=${PROF_CMD:-bench.py}
 echo "$ARGS" > "$OUT/bench_args.txt"
