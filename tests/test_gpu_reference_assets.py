@@ -100,6 +100,29 @@ def test_config2_suzanne_glb_512_64_samples(ctx):
     assert p >= 45.0, p
 
 
+def test_config2_as_worded_suzanne_with_sun_and_trail_hdr(ctx):
+    """Configuration 2 as BASELINE.json words it: "sun + trail.hdr HDRI".  The live shader has no sun
+    (the block is commented out, shader.wgsl:916-937), so this is the opt-in enable_sun = 1 against
+    the oracle's restatement of that block, from a camera that fills the frame with the head."""
+    s, a = load_reference_scene("suzanne")
+    v = a["tris"]["v"][:, :, :3].reshape(-1, 3)
+    c, e = (v.min(0) + v.max(0)) / 2, (v.max(0) - v.min(0)).max()
+    s.add_camera(host.Camera.look((c[0] + e, c[1], c[2]), yaw=np.pi, pitch=0.0, fovy=np.radians(60.0), focus=e))
+    p = device.default_params(enable_sun=1)
+    got, ref = both(ctx, s, a, (512, 512), params=p, camera_idx=1)
+    assert ref["counters"]["shadow_rays"] > 10000
+    check_frame(got, ref)
+    assert abs(got["counters"]["shadow_rays"] - ref["counters"]["shadow_rays"]) <= max(4, 2e-3 * ref["counters"]["shadow_rays"])
+    p = device.default_params(enable_sun=1)
+    got, ref = both(ctx, s, a, (512, 512), n=64, params=p, taps=False, camera_idx=1)
+    assert np.all(got["accum"][..., 3] == 64.0)
+    db = psnr(tonemapped(got["accum"]), tonemapped(ref["accum"]))
+    assert db >= 45.0, db
+    # and the sun does light the head: brighter than the HDRI-only render of the same frames
+    dark, _ = both(ctx, s, a, (512, 512), n=64, taps=False, camera_idx=1)
+    assert float(got["accum"][..., :3].sum()) > 1.02 * float(dark["accum"][..., :3].sum())
+
+
 @pytest.mark.parametrize("name,res", [("simple_terrain", (768, 384)), ("simple_with_camera", (640, 360))])
 def test_scenes_with_gltf_camera_and_node_transforms(ctx, name, res):
     s, a = load_reference_scene(name)
