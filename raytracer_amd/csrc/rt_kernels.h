@@ -579,7 +579,13 @@ __device__ __forceinline__ float hit_aabb6(f3 o, f3 idir, float nx, float ny, fl
 #ifndef RT_EXTEND_WAVES_TREE
 #define RT_EXTEND_WAVES_TREE 7
 #endif
-__host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi ? RT_LDS_LEVELS_MULTI : RT_LDS_LEVELS_SINGLE; }
+// The TREE instantiation keeps its walk state (the lane's position in the pyramid and a byte of
+// pending children per level: three dwords per lane) in LDS as well, which is what keeps it out of
+// scratch at 72 registers; three stack levels make room for it.
+#ifndef RT_LDS_LEVELS_TREE
+#define RT_LDS_LEVELS_TREE 13u
+#endif
+__host__ __device__ constexpr uint32_t rt_lds_levels(bool multi, bool tree = false) { return tree ? RT_LDS_LEVELS_TREE : multi ? RT_LDS_LEVELS_MULTI : RT_LDS_LEVELS_SINGLE; }
 #define RT_MAX_STACK 64u
 
 // trace(), shader.wgsl:598-627, with trace_bvh (442-525) inlined as a per-lane state machine.
@@ -634,17 +640,28 @@ __host__ __device__ constexpr uint32_t rt_lds_levels(bool multi) { return multi 
 // last entry.
 #define RT_LIST_SCANNING 0xFFu
 template <bool COUNT, bool DEEP, bool MULTI, bool ANYHIT = false, bool TREE = false, bool LIST = false>
-__global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
+__global__ __launch_bounds__(256, (TREE && ANYHIT && DEEP) ? RT_EXTEND_WAVES_TREE - 1 : TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEND_WAVES_MULTI : RT_EXTEND_WAVES_SINGLE) void k_extend(ExtArgs a) {
+    // (shadow rays through the pyramid with a deep stack: the one instantiation that does not fit 72
+    // registers without scratch; one wave per SIMD fewer gives it 80)
     static_assert(!TREE || MULTI, "TREE is a variant of MULTI");
     static_assert(!LIST || (MULTI && !TREE), "LIST is a variant of the scan");
     constexpr bool SCAN = MULTI && !TREE;
-    constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI);
+    constexpr uint32_t RT_LDS_LEVELS = rt_lds_levels(MULTI, TREE);
     __shared__ uint32_t lds_tlas_dir[1 + 2 * RT_TLAS_MAX_LEVELS];
     if (TREE) {
         if (threadIdx.x < 1u + 2u * RT_TLAS_MAX_LEVELS) lds_tlas_dir[threadIdx.x] = a.tlas_dir[threadIdx.x];
         __syncthreads();
     }
     __shared__ uint32_t lds_stack[4 * RT_LDS_LEVELS * RT_WAVE];
+    // TREE: byte L of a lane's two dwords = children of the lane's record at pyramid level L still to visit
+    __shared__ uint32_t lds_tl_pending[TREE ? 3 * 256 : 1]; // + the lane's position: level << 28 | record
+    uint32_t* const tlp = lds_tl_pending + (TREE ? threadIdx.x : 0u);
+    auto pend_get = [&](uint32_t lvl) -> uint32_t { return (tlp[(lvl >> 2) * 256u] >> (8u * (lvl & 3u))) & 0xFFu; };
+    auto pend_clear_bit = [&](uint32_t lvl, uint32_t k) { tlp[(lvl >> 2) * 256u] &= ~(1u << (8u * (lvl & 3u) + k)); };
+    auto pend_set = [&](uint32_t lvl, uint32_t m) {
+        uint32_t& w = tlp[(lvl >> 2) * 256u];
+        w = (w & ~(0xFFu << (8u * (lvl & 3u)))) | (m << (8u * (lvl & 3u)));
+    };
     // world-space origin and direction of each lane's ray, read again at every primitive it enters
     __shared__ float lds_ray[6 * 256];
     float* const ray = lds_ray + threadIdx.x;
@@ -684,8 +701,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
     uint32_t slot = 0;
     uint32_t mask[4] = {0, 0, 0, 0};
     uint32_t cb = 0; // first primitive of the 128-primitive chunk the mask describes (MULTI); TREE: the next candidate primitive
-    uint32_t tl = 0;                  // TREE: level << 28 | record of the pyramid the lane stands at
-    unsigned long long tl_pending = 0; // TREE: byte L = children of the lane's record at level L still to visit
+    uint32_t& tl = tlp[TREE ? 512 : 0]; // TREE: level << 28 | record of the pyramid the lane stands at (in LDS, like the pending bytes)
     uint32_t li = 0;                  // LIST: next entry of the ray's candidate list, or RT_LIST_SCANNING once the scan has taken over
     uint32_t scan_from = 0;           // LIST: first primitive the scan still has to look at
     unsigned long long cmask = ~0ull; // bit c: the ray meets the union bound of chunk c (c < 64)
@@ -735,14 +751,14 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
             const uint32_t top = lds_tlas_dir[0];
             for (;;) {
                 const uint32_t lvl = tl >> 28, rec = tl & 0x0FFFFFFFu;
-                const uint32_t pend = (uint32_t)(tl_pending >> (8u * lvl)) & 0xFFu;
+                const uint32_t pend = pend_get(lvl);
                 if (pend == 0u) {
                     if (lvl >= top) { retire(); break; }
                     tl = ((lvl + 1u) << 28) | (rec >> 3);
                     continue;
                 }
                 const uint32_t k = (uint32_t)__builtin_ctz(pend);
-                tl_pending &= ~(1ull << (8u * lvl + k));
+                pend_clear_bit(lvl, k);
                 const uint32_t ent = rec * 8u + k;
                 if (lvl == 0u) { cb = ent; st = ST_PRIM; break; }
                 tl = ((lvl - 1u) << 28) | ent;
@@ -775,7 +791,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
     };
     // the traversal of primitive p ended: shader.wgsl:610-614
     auto finish = [&]() {
-        if (best_i >= 0) {
+        if (!ANYHIT && best_i >= 0) { // (a shadow ray that finds a triangle retires on the spot, in the leaf step)
             float* rec = reinterpret_cast<float*>(a.hits + slot);
             rec[0] = best_t / scale;
             rec[1] = __int_as_float(best_i);
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                         cb = 0;
                         if (SCAN) cmask = ~0ull;
                         st = ST_SCAN;
-                        if (TREE) { tl = lds_tlas_dir[0] << 28; tl_pending = 0ull; st = ST_TLAS; } // at the top record, untested
+                        if (TREE) { tl = lds_tlas_dir[0] << 28; tlp[0] = 0u; tlp[256] = 0u; st = ST_TLAS; } // at the top record, untested
                         if (LIST) { li = 0u; scan_from = 0u; }
                         fresh = true;
 #ifdef RT_PROBE
@@ -1035,7 +1051,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                 // the last record of a level is padded to eight: drop what does not exist
                 const uint32_t have = lds_tlas_dir[1u + RT_TLAS_MAX_LEVELS + lvl] - rec * 8u;
                 if (have < 8u) m &= (1u << have) - 1u;
-                tl_pending = (tl_pending & ~(0xFFull << (8u * lvl))) | ((unsigned long long)m << (8u * lvl));
+                pend_set(lvl, m);
                 advance();
             }
         } else if (n_inner >= n_prim && n_inner >= n_leaf) {
@@ -1077,8 +1093,10 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
 #pragma unroll
                     for (int x = 0; x < RT_DIAG_EXTRA_LOADS; x++) asm volatile("" :: "v"(xv[x])); // keeps the registers until here
 #endif
-                    const bool lmiss = (left < -0.5f || left > best_t);
-                    const bool rmiss = (right < -0.5f || right > best_t);
+                    // a shadow ray has no distance bound: its best_t is +inf whatever the primitive (not kept in a register)
+                    const float bound_t = ANYHIT ? __builtin_inff() : best_t;
+                    const bool lmiss = (left < -0.5f || left > bound_t);
+                    const bool rmiss = (right < -0.5f || right > bound_t);
                     if (lmiss && rmiss) {
                         pop_or_finish();
                     } else {
@@ -1110,6 +1128,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
 #ifdef RT_PROBE
                 pr_steps++;
 #endif
+                if (ANYHIT) best_i = -1; // nothing found so far, or the ray would have retired: the register is free between rounds
                 const float4* tp = rec16(tris, cur_first * 3u);
                 // 12-byte loads: the fourth lane of a triangle's rows is padding, and the return path
                 // charges a wave-level load by its width
@@ -1120,7 +1139,7 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                     if (COUNT) c_tri++;
                     float u, v;
                     const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
-                    if (t >= 0.0f && t < best_t) {
+                    if (t >= 0.0f && (ANYHIT || t < best_t)) { // a finite t is below a shadow ray's +inf
                         bool accept = true;
                         if (!ANYHIT && pm >= (1u << RT_PM_MODE_SHIFT)) { // shader.wgsl:464-487
                             if (COUNT) c_alpha++;
@@ -1198,12 +1217,11 @@ __global__ __launch_bounds__(256, TREE ? RT_EXTEND_WAVES_TREE : MULTI ? RT_EXTEN
                 if (COUNT) c_prims++;
                 const float troot = hit_aabb_s(lo, lidir, r0, r1);
                 const uint32_t root_first = __float_as_uint(r1.z), root_count = __float_as_uint(r1.w);
-                best_t = closest_t * scale;
-                best_i = -1;
+                if (!ANYHIT) { best_t = closest_t * scale; best_i = -1; }
                 sp = 0;
                 if (troot < -0.5f) { // shader.wgsl:448
                     advance();
-                } else if (nested && troot > best_t) {
+                } else if (!ANYHIT && nested && troot > best_t) {
                     // The root (an inner node whose children lie inside its box) is entered beyond
                     // the best hit so far.  The reference would take one inner step here, find
                     // both children at least as far, hence beyond best_t, and leave with nothing:

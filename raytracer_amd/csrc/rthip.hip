@@ -1075,7 +1075,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const bool multi = c->sc.n_chunks > 1u;
     const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : (c->lists ? EXT_LIST : EXT_SCAN));
-    const bool deep = P.stack_depth > rt_lds_levels(multi);
+    const bool deep = P.stack_depth > rt_lds_levels(multi, c->tree);
     // with a handful of primitives the candidate test saves less than it costs
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     bool cull_camera = true;
@@ -1112,7 +1112,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             c->cand_cap = c->queue_cap * c->list_len;
         }
         if (deep) { // stack levels beyond the LDS part: one dword column per thread of the extend grid
-            const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi)) * ext_grid * 256;
+            const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi, c->tree)) * ext_grid * 256;
             if (c->spill_words < words) {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 free_dev_t(c->spill);
@@ -1419,13 +1419,13 @@ int rthip_trace_rays(rthip_ctx* c, const float* rays6, uint32_t* seeds, uint64_t
     const bool timing = (P.flags & RTHIP_FLAG_TIMING) != 0;
     const bool multi = c->sc.n_chunks > 1u;
     const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : (c->lists ? EXT_LIST : EXT_SCAN));
-    const bool deep = P.stack_depth > rt_lds_levels(multi);
+    const bool deep = P.stack_depth > rt_lds_levels(multi, c->tree);
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const int blocks = extend_occupancy(count, deep, ext_mode);
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * blocks, (n + 255) / 256);
     if (deep) {
-        const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi)) * grid * 256;
+        const uint64_t words = (uint64_t)(RT_MAX_STACK - rt_lds_levels(multi, c->tree)) * grid * 256;
         if (c->spill_words < words) {
             (void)hipStreamSynchronize(c->stream);
             free_dev_t(c->spill);
@@ -1524,7 +1524,7 @@ int rthip_trace_rays_noalloc(rthip_ctx* c, const float* d_rays6, uint32_t* d_see
     const bool count = (P.flags & RTHIP_FLAG_COUNTERS) != 0;
     const bool multi = c->sc.n_chunks > 1u;
     const ExtMode ext_mode = !multi ? EXT_SINGLE : (c->tree ? EXT_TREE : EXT_SCAN);
-    const bool deep = P.stack_depth > rt_lds_levels(multi);
+    const bool deep = P.stack_depth > rt_lds_levels(multi, c->tree);
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     const NanWalk& nanw = nan_walk(c, std::min<uint32_t>(P.stack_depth, RT_MAX_STACK));
     const int blocks = extend_occupancy(count, deep, ext_mode);

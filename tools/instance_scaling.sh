@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 out=gpurun_out/instance_scaling.jsonl
 : > $out
 run() {
-  timeout -k 10 300 python bench.py --workload terrain --tiles $1 --terrain-n 16 --instanced $2 --steps 64 --warmup 64 --no-cpu-baseline --no-single-frame > gpurun_out/inst_one.json
+  timeout -k 10 300 python bench.py --workload terrain --tiles $1 --terrain-n 16 --instanced $2 --steps 64 --warmup 64 --no-cpu-baseline --no-single-frame --no-hbm-case > gpurun_out/inst_one.json
   python - "$1" "$2" <<'PY' >> $out
 import json,sys
 j=json.loads(open('gpurun_out/inst_one.json').read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@
 #   bash tools/side_benches.sh   -> gpurun_out/side/*.json
 set -e
 mkdir -p gpurun_out/side
-B="python bench.py --no-cpu-baseline --no-single-frame"
+B="python bench.py --no-cpu-baseline --no-single-frame --no-hbm-case"
 timeout -k 10 300 $B --res 3840x2160 > gpurun_out/side/atrium_4k.json
 echo atrium_4k done
 timeout -k 10 300 $B --workload blob --res 512x512 --max-bounces 8 > gpurun_out/side/blob.json

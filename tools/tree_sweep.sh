@@ -7,7 +7,7 @@ out=gpurun_out/tree_sweep.jsonl
 for tiles in ${TILES:-24 64 90 180}; do
   for min in 4000000000 128; do
     echo "tiles=$tiles tree_min=$min"
-    RTHIP_TUNING=1 RTHIP_TREE_MIN_PRIMS=$min timeout -k 10 200 python bench.py --workload terrain --tiles $tiles --terrain-n 16 --instanced ${EXTRA} --view ${VIEW:-ground} --steps 64 --warmup 64 --no-cpu-baseline --no-single-frame > gpurun_out/tree_one.json
+    RTHIP_TUNING=1 RTHIP_TREE_MIN_PRIMS=$min timeout -k 10 200 python bench.py --workload terrain --tiles $tiles --terrain-n 16 --instanced ${EXTRA} --view ${VIEW:-ground} --steps 64 --warmup 64 --no-cpu-baseline --no-single-frame --no-hbm-case > gpurun_out/tree_one.json
     python - "$tiles" "$min" <<'PY' >> $out
 import json,sys
 j=json.loads(open('gpurun_out/tree_one.json').read().strip().splitlines()[-1])
