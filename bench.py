@@ -458,6 +458,7 @@ def main():
         lane_loads, wave_loads = extend_lane_loads(counters)
         active = max(1, min(64, int(round(lane_loads / max(wave_loads, 1)))))
         ceiling = ctx.gather_ceiling(active)                 # lane-loads / s, measured now, on this GPU
+        ceiling_wide = ctx.gather_ceiling(active, 128)       # the same for 128-byte records (a 4-wide step with exact boxes)
         lane_rate = (lane_loads / launches) / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         roof = {
             # A byte-moving f32 / integer kernel with no contraction: HBM is the roofline it is classed
@@ -496,6 +497,9 @@ def main():
                 "active_lanes_per_wave_load": active,
                 "lane_loads_per_ray": round(lane_loads / max(rays_local, 1), 1),
                 "ceiling_source": "rthip_gather_ceiling, this run, this GPU: 64-byte records out of the L1, 8 waves per SIMD, independent steps",
+                # for the record: the same pipeline fed 128-byte records (two lines per lane and step),
+                # which is what a 4-wide tree with exact f32 boxes would fetch per step
+                "ceiling_with_128_byte_records": round(ceiling_wide / 1e9, 1),
             },
         }
         if pmc and avg_ms > 0:

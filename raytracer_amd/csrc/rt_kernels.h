@@ -1669,22 +1669,30 @@ __global__ __launch_bounds__(256) void k_unpack_hits(const float4* hits, uint32_
 // ------------------------------------------------------------------ measurement aid: the gather ceiling
 
 // What a CU's vector-memory pipeline sustains for the access shape of the extend stage when memory
-// latency is out of the picture: every ACTIVE lane of a wave (lanes chosen by `mask`) reads the four
-// 16-byte pieces of a 64-byte record of its own per iteration -- the shape of an inner-node step --
-// from a 16 KiB table that stays in the L1; the loads of an iteration do not depend on each other
-// and eight waves share a SIMD, so the time is the throughput of the address / tag / return path,
-// not a latency.  The record a lane reads changes every iteration (a small LCG), as the nodes of a
-// traversal do.
+// latency is out of the picture: every ACTIVE lane of a wave (lanes chosen by `mask`) reads the
+// 16-byte pieces of a record of its own per iteration -- four of a 64-byte record: the shape of an
+// inner-node step; or (WIDE) eight of a 128-byte record: what a step of a 4-wide tree with exact f32
+// boxes would read -- from a 16 KiB table that stays in the L1; the loads of an iteration do not
+// depend on each other and eight waves share a SIMD, so the time is the throughput of the address /
+// tag / return path, not a latency.  The record a lane reads changes every iteration (a small LCG),
+// as the nodes of a traversal do.
+template <bool WIDE>
 __global__ __launch_bounds__(256, 8) void k_gather_ceiling(const float4* table, unsigned long long mask, uint32_t iters, float* sink) {
+    constexpr uint32_t PIECES = WIDE ? 8u : 4u;         // float4 per record
+    constexpr uint32_t RECORDS = 16384u / (16u * PIECES);
     const uint32_t lane = lane_id();
     float acc = 0.0f;
     if ((mask >> lane) & 1ull) {
-        uint32_t idx = (threadIdx.x * 7u + blockIdx.x * 13u) & 255u; // 256 records of 64 bytes
+        uint32_t idx = (threadIdx.x * 7u + blockIdx.x * 13u) & (RECORDS - 1u);
         for (uint32_t i = 0; i < iters; i++) {
-            const float4* r = table + idx * 4u;
+            const float4* r = table + idx * PIECES;
             const float4 a = r[0], b = r[1], c = r[2], d = r[3];
             acc += (a.x + b.y) + (c.z + d.w);
-            idx = (idx * 5u + 1u) & 255u;
+            if (WIDE) {
+                const float4 e = r[4], f = r[5], g = r[6], h = r[7];
+                acc += (e.x + f.y) + (g.z + h.w);
+            }
+            idx = (idx * 5u + 1u) & (RECORDS - 1u);
         }
     }
     if (acc == 12345.678f) sink[0] = acc; // never true: keeps the loads

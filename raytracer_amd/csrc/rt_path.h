@@ -39,6 +39,10 @@
 #ifndef RT_PATH_HEAVY_DIV
 #define RT_PATH_HEAVY_DIV 2u
 #endif
+// camera paths left per wave of the grid below which a wave reserves only what its free lanes take at once
+#ifndef RT_PATH_EXACT_LEFT
+#define RT_PATH_EXACT_LEFT 0xFFFFFFFFu
+#endif
 #ifndef RT_PATH_RUN_SLOTS
 #define RT_PATH_RUN_SLOTS 64u
 #endif
@@ -68,6 +72,12 @@ struct PathArgs {
     float*    tap_t;
     uint32_t* tap_seed;
     uint32_t* watchdog;       // set to 1 by a wave that ran into RT_PATH_WATCHDOG
+    // Longest first: camera paths are handed out in runs of 64 slots; run r of the call renders the
+    // slots of run order[r] (a permutation of the runs, expensive ones first; null = as they come),
+    // and what a run's paths cost (wave rounds from their first to their last, summed) is added to
+    // cost[its run], from which the order of the next call on the same view is made.
+    const uint32_t* order;
+    uint32_t* cost;
     unsigned long long* counters;
     unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped; // see ExtArgs
 #ifdef RT_PROBE
@@ -81,6 +91,8 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     __shared__ float lds_ray[6 * 256];   // world-space origin and direction of the lane's current ray
     __shared__ float lds_path[6 * 256];  // throughput and lighting of the lane's path
     __shared__ float lin_lut[256];
+    __shared__ uint32_t lds_meta[2 * 256]; // per lane: the run its path came from, and the wave's round count when it started
+    uint32_t* const meta = lds_meta + threadIdx.x;
     lin_lut[threadIdx.x & 255u] = powf((float)(threadIdx.x & 255u) / 255.0f, 2.2f); // as k_shade
     __syncthreads();
     float* const ray = lds_ray + threadIdx.x;
@@ -338,6 +350,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                         a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
                     }
                     if (a.tap && pix < a.n_pixels) a.tap_seed[pix] = seed;
+                    if (a.cost) atomicAdd(a.cost + meta[0], iter - meta[256]);
                     st = ST_DONE;
                 }
             }
@@ -349,9 +362,14 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
             if (!drained) {
                 const unsigned long long done_m = __ballot(st == ST_DONE);
                 if (done_m != 0ull && run_next == run_end) {
-                    // guided reservation, as in k_extend: ever smaller runs towards the end of the call
+                    // As many slots as lanes are free right now (one atomic per path round that hands
+                    // out paths): a camera path that waits in a wave's private run for one of that
+                    // wave's lanes, while lanes elsewhere idle, is what the end of the launch would
+                    // wait for.  (Whole runs of 64 per atomic until RT_PATH_EXACT_LEFT paths per wave
+                    // are left, then exact: 3.20 ms per frame with whole runs throughout, 3.16 / 3.13 /
+                    // 3.12 with the switch at 64 / 256 / never whole runs.)
                     const uint32_t left = n > cursor_seen ? n - cursor_seen : 0u;
-                    const uint32_t want = min(RT_PATH_RUN_SLOTS, max(RT_RUN_MIN, left / (RT_RUN_DIV * 4u * gridDim.x)));
+                    const uint32_t want = left > (unsigned long long)RT_PATH_EXACT_LEFT * 4u * gridDim.x ? RT_PATH_RUN_SLOTS : min(RT_PATH_RUN_SLOTS, (uint32_t)__popcll(done_m));
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(a.cursor, want);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -374,7 +392,11 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                     const uint32_t avail = run_end - run_next;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_m, 0u));
                     if (st == ST_DONE && rank < avail) {
-                        if (camera_path(a.gen, run_next + rank, o, d, seed, pix)) {
+                        const uint32_t s_in = run_next + rank;
+                        const uint32_t run = a.order ? a.order[s_in >> 6] : s_in >> 6;
+                        if (camera_path(a.gen, (run << 6) | (s_in & 63u), o, d, seed, pix)) {
+                            meta[0] = run;
+                            meta[256] = iter;
                             if (COUNT) c_paths++;
                             bounce = 0u;
                             pth[0] = 1.0f; pth[256] = 1.0f; pth[512] = 1.0f;    // throughput, shader.wgsl:891
@@ -507,4 +529,49 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
             atomicAdd(&a.counters[C_BATCHES], r_batch);
         }
     }
+}
+
+// ------------------------------------------------------------------ longest first
+
+// The order in which the next call on this view hands out its runs of camera paths: by what the runs
+// cost in the call before, expensive first.  A persistent launch ends when its last paths do, and
+// paths that start late through foliage keep a few waves busy long after the others have gone; the
+// same paths started first are over while there is still work for everybody.  Whatever the costs
+// are, `order` comes out a permutation of 0 .. n_runs - 1 (a counting sort over 256 cost levels:
+// every run gets exactly one place), and the result of a render does not depend on it.  One block;
+// also clears the costs for the next call.
+__global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
+    __shared__ uint32_t bucket[256];
+    __shared__ uint32_t red[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t mx = 0;
+    for (uint32_t i = t; i < n_runs; i += 1024u) mx = max(mx, cost[i]);
+    red[t] = mx;
+    if (t < 256u) bucket[t] = 0u;
+    __syncthreads();
+    for (uint32_t w = 512u; w > 0u; w >>= 1) {
+        if (t < w) red[t] = max(red[t], red[t + w]);
+        __syncthreads();
+    }
+    const uint32_t top = red[0];
+    // level 0 = the most expensive
+    auto level = [&](uint32_t c) -> uint32_t { return top == 0u ? 0u : 255u - (uint32_t)(((unsigned long long)c * 255ull) / top); };
+    for (uint32_t i = t; i < n_runs; i += 1024u) atomicAdd(&bucket[level(cost[i])], 1u);
+    __syncthreads();
+    if (t == 0u) { // exclusive prefix over the 256 levels
+        uint32_t acc = 0u;
+        for (uint32_t b = 0; b < 256u; b++) { const uint32_t c = bucket[b]; bucket[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n_runs; i += 1024u) {
+        const uint32_t c = cost[i];
+        order[atomicAdd(&bucket[level(c)], 1u)] = i;
+        cost[i] = 0u;
+    }
+}
+
+// the order of a first call: as the runs come
+__global__ __launch_bounds__(256) void k_order_identity(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_runs) { order[i] = i; cost[i] = 0u; }
 }

@@ -128,6 +128,10 @@ struct rthip_ctx {
 
     unsigned long long* d_counters = nullptr;
 
+    uint32_t* path_cost = nullptr;   // k_path: what each run of camera paths cost in the last short call, and the
+    uint32_t* path_order = nullptr;  // order (expensive first) in which the next one hands them out
+    uint64_t  path_runs_cap = 0;
+    uint32_t  order_runs = 0, order_res_x = 0, order_res_y = 0, order_frames = 0, order_spread = 0; // what the order was made for (0 runs: none)
     uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
     uint32_t* watchdog_dev = nullptr;  // the same word as the device sees it
     unsigned char* noalloc_scratch = nullptr; // this device's copy of `scratch` (rthip_trace_rays_noalloc)
@@ -198,6 +202,10 @@ void free_scene(rthip_ctx* c) {
 void free_work_buffers(rthip_ctx* c) {
     free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
     free_dev_t(c->cand_lists);
+    free_dev_t(c->path_cost);
+    free_dev_t(c->path_order);
+    c->path_runs_cap = 0;
+    c->order_runs = 0;
     c->cand_cap = 0;
     c->shadow_cap = 0;
     c->spill_words = 0;
@@ -954,6 +962,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->node_index_map.swap(map);
     c->have_scene = true;
     c->reject_hist = 1;
+    c->order_runs = 0; // what the runs of camera paths cost in the old scene says nothing about this one
     return RTHIP_OK;
 }
 
@@ -1064,6 +1073,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     int path_blocks_env = 0;
     if (const char* e = knob(c, "RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
     const bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
+    int lpt_env = 1;
+    if (const char* e = knob(c, "RTHIP_PATH_LONGEST_FIRST")) lpt_env = std::atoi(e); // experiment knob: 0 = runs as they come
 
     PathQueue q[2];
     for (int k = 0; k < 2; k++) {
@@ -1171,6 +1182,30 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             if (path_blocks_env > 0) pblocks = std::min(pblocks, path_blocks_env);
             const uint32_t pgrid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * pblocks, (slots + 255) / 256);
             pa.watchdog = c->watchdog_dev;
+            // Longest first: the runs of camera paths in the order of what they cost in the last
+            // call of this shape (resolution, frames per call).  A new shape, a new scene or a
+            // discarded history (reject_hist: the view has changed) starts from the plain order.
+            const uint32_t n_runs = (uint32_t)(slots >> 6);
+            if (lpt_env != 0) {
+                if (c->path_runs_cap < n_runs) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    free_dev_t(c->path_cost);
+                    free_dev_t(c->path_order);
+                    c->path_runs_cap = 0;
+                    c->order_runs = 0;
+                    HIP_TRY(c, hipMalloc((void**)&c->path_cost, sizeof(uint32_t) * n_runs));
+                    HIP_TRY(c, hipMalloc((void**)&c->path_order, sizeof(uint32_t) * n_runs));
+                    c->path_runs_cap = n_runs;
+                }
+                const bool same = c->order_runs == n_runs && c->order_res_x == c->res_x && c->order_res_y == c->res_y && c->order_frames == nf &&
+                                  c->order_spread == pa.gen.spread_shift && !overwrite;
+                if (!same) {
+                    hipLaunchKernelGGL(k_order_identity, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_order, n_runs);
+                    c->order_runs = n_runs; c->order_res_x = c->res_x; c->order_res_y = c->res_y; c->order_frames = nf; c->order_spread = pa.gen.spread_shift;
+                }
+                pa.order = c->path_order;
+                pa.cost = c->path_cost;
+            }
 #ifdef RT_PROBE
             // diagnostic build only (tools/path_probe.py): per-wave records of this launch appended to $RTHIP_PROBE_FILE
             static unsigned long long* path_probe_buf = nullptr;
@@ -1201,6 +1236,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
                                    (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
             }
+            if (pa.order) hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, c->stream, c->path_cost, c->path_order, n_runs);
             c->reject_hist = 0; // main.rs:403
             if (tap_group) c->taps_valid = true;
             continue;
@@ -1775,9 +1811,11 @@ int rthip_copy_bandwidth(rthip_ctx* c, uint64_t bytes, uint32_t repeats, double*
     return RTHIP_OK;
 }
 
-int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, double* lane_loads_per_s) {
+int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, uint32_t record_bytes, double* lane_loads_per_s) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!lane_loads_per_s || active_lanes == 0 || active_lanes > 64) return fail(c, RTHIP_ERR_INVALID, "gather_ceiling: null result, or active_lanes outside 1..64");
+    if (record_bytes != 64 && record_bytes != 128) return fail(c, RTHIP_ERR_INVALID, "gather_ceiling: record_bytes %u is neither 64 nor 128", record_bytes);
+    const bool wide = record_bytes == 128;
     DeviceGuard g(c->device);
     // `active_lanes` lanes spread over the wave by a fixed permutation (scattered, as the lanes that
     // share a step kind are)
@@ -1793,11 +1831,14 @@ int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, double* lane_loads
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_gather_ceiling, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, 50u, sink); // untimed: code and table in the caches
+        // untimed first: code and table in the caches
+        if (wide) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, 50u, sink);
+        else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, 50u, sink);
         e = hipEventRecord(e0, c->stream);
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_gather_ceiling, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, iters, sink);
+        if (wide) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, iters, sink);
+        else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, iters, sink);
         e = hipEventRecord(e1, c->stream);
     }
     if (e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1809,8 +1850,8 @@ int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, double* lane_loads
     if (table) (void)hipFree(table);
     if (sink) (void)hipFree(sink);
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "gather_ceiling: %s", hipGetErrorString(e));
-    // blocks x 4 waves x iters iterations x 4 loads, each by active_lanes lanes
-    *lane_loads_per_s = ms > 0.0f ? (double)blocks * 4.0 * iters * 4.0 * active_lanes / ((double)ms * 1e-3) : 0.0;
+    // blocks x 4 waves x iters iterations x 4 (or 8) loads, each by active_lanes lanes
+    *lane_loads_per_s = ms > 0.0f ? (double)blocks * 4.0 * iters * (wide ? 8.0 : 4.0) * active_lanes / ((double)ms * 1e-3) : 0.0;
     return RTHIP_OK;
 }
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Soak run (not collected by pytest): one context through many scene uploads, resolutions, frame-group
-sizes and ray queries in a row; free device memory must come back to where it was once the context is
-closed, and must not creep while it lives.    python tests/tools/soak_gpu.py [--rounds 40]"""
+"""Soak run: one context through many scene uploads, resolutions, frame-group sizes and ray queries in
+a row; free device memory must come back to where it was once the context is closed, and must not
+creep while it lives.    python tests/tools/soak_gpu.py [--rounds 40]
+tests/test_gpu_soak.py runs a short form of it (soak(rounds=8)) under pytest."""
 import argparse
 import os
 import sys
@@ -15,10 +16,9 @@ import torch  # noqa: E402  (before the device library opens the GPU)
 from raytracer_amd import device, procedural  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rounds", type=int, default=40)
-    args = ap.parse_args()
+def soak(n_rounds, log=print):
+    """Two contexts one after the other, n_rounds each.  Returns the free device memory (bytes) before,
+    the lowest seen while each context lived, and after each was closed."""
     rng = np.random.default_rng(1)
     torch.cuda.init()
     free0 = torch.cuda.mem_get_info()[0]
@@ -47,17 +47,25 @@ def main():
                 c.trace_rays(o, d)
                 c.resolve()
                 seen.append(torch.cuda.mem_get_info()[0])
-                print(f"round {r}: scene {k} ({arrays[k]['prims'].shape[0]} prims, {c.candidate_walk()}) res {res}: free {seen[-1] / 2**20:.0f} MiB", flush=True)
+                log(f"round {r}: scene {k} ({arrays[k]['prims'].shape[0]} prims, {c.candidate_walk()}) res {res}: free {seen[-1] / 2**20:.0f} MiB")
         finally:
             c.close()
         return min(seen)
 
     # the first context also pays for what the runtime keeps for the process (code objects, the library's
     # fixed work array, kernel scratch): only the second one shows what the library itself leaves behind
-    low1 = phase(args.rounds)
+    low1 = phase(n_rounds)
     free1 = torch.cuda.mem_get_info()[0]
-    low2 = phase(args.rounds)
+    low2 = phase(n_rounds)
     free2 = torch.cuda.mem_get_info()[0]
+    return free0, low1, free1, low2, free2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=40)
+    args = ap.parse_args()
+    free0, low1, free1, low2, free2 = soak(args.rounds, log=lambda m: print(m, flush=True))
     print(f"free before {free0 / 2**20:.0f} MiB; first context: lowest {low1 / 2**20:.0f}, after close {free1 / 2**20:.0f}; "
           f"second context: lowest {low2 / 2**20:.0f}, after close {free2 / 2**20:.0f} MiB")
     return 0 if free1 - free2 < (8 << 20) else 1

@@ -38,7 +38,7 @@ def main():
     ctx.upload_scene(arrays)
     ctx.set_frame_uniforms(scene.frame_uniforms(res, frame=1, reject_hist=1))
     p = device.default_params(max_bounces=args.max_bounces, term_prob=args.term_prob, stack_depth=args.stack_depth)
-    for f in range(3):
+    for f in range(6):   # the order of the runs (longest first) comes from the call before
         ctx.render(1 + f * frames, frames, 1, p)
     ctx.synchronize()
     if os.path.exists(probe_file):
