@@ -457,8 +457,12 @@ def main():
         pmc = pmc_figures(key)
         lane_loads, wave_loads = extend_lane_loads(counters)
         active = max(1, min(64, int(round(lane_loads / max(wave_loads, 1)))))
-        ceiling = ctx.gather_ceiling(active)                 # lane-loads / s, measured now, on this GPU
-        ceiling_wide = ctx.gather_ceiling(active, 128)       # the same for 128-byte records (a 4-wide step with exact boxes)
+        # lane-loads / s, measured now, on this GPU, for four access shapes: one or two 64-byte records
+        # (the inner-node step's) or 128-byte records (a 4-wide step with exact boxes) per lane and step
+        shapes = {"64-byte records, one in flight": (64, 1), "64-byte records, two in flight": (64, 2),
+                  "128-byte records, one in flight": (128, 1), "128-byte records, two in flight": (128, 2)}
+        ceilings = {k: ctx.gather_ceiling(active, *v) for k, v in shapes.items()}
+        ceiling = max(ceilings.values())
         lane_rate = (lane_loads / launches) / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         roof = {
             # A byte-moving f32 / integer kernel with no contraction: HBM is the roofline it is classed
@@ -486,8 +490,10 @@ def main():
             # (address unit, L1 tag look-up, data return).  Unit = lane-loads: one lane's 16-byte load
             # (a 12-byte load counts 3/4).  achieved = the loads the traversal counters imply (4 per inner
             # step, 3 x 3/4 per triangle test, 6 per primitive entered, 3 per ray fetched) per second of k_extend;
-            # ceiling = rthip_gather_ceiling at the same number of active lanes per wave-level load:
-            # the same access shape from an L1-resident table, no dependence between steps.
+            # ceiling = the best of rthip_gather_ceiling's access shapes at the same number of active lanes
+            # per wave-level load: records of the traversal's size from an L1-resident table, no
+            # dependence between steps (the 64-byte shape with one record in flight, which is the inner
+            # step's own, is reported beside it: the stage can pass that one, since its rounds overlap).
             "binding": {
                 "resource": "CU vector-memory pipeline: lane-loads of the divergent record fetches (address unit, L1 look-up, data return)",
                 "unit": "Glane-loads/s (16-byte loads)",
@@ -496,10 +502,10 @@ def main():
                 "frac": round(lane_rate / ceiling, 4) if ceiling > 0 else None,
                 "active_lanes_per_wave_load": active,
                 "lane_loads_per_ray": round(lane_loads / max(rays_local, 1), 1),
-                "ceiling_source": "rthip_gather_ceiling, this run, this GPU: 64-byte records out of the L1, 8 waves per SIMD, independent steps",
-                # for the record: the same pipeline fed 128-byte records (two lines per lane and step),
-                # which is what a 4-wide tree with exact f32 boxes would fetch per step
-                "ceiling_with_128_byte_records": round(ceiling_wide / 1e9, 1),
+                "ceiling_source": "rthip_gather_ceiling, this run, this GPU: the best of four access shapes out of the L1, 8 waves per SIMD, independent steps",
+                "ceiling_by_shape": {k: round(v / 1e9, 1) for k, v in ceilings.items()},
+                # a 4-wide tree with exact f32 boxes would fetch 128 bytes per step
+                "ceiling_with_128_byte_records": round(ceilings["128-byte records, one in flight"] / 1e9, 1),
             },
         }
         if pmc and avg_ms > 0:

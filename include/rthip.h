@@ -242,14 +242,14 @@ int rthip_copy_bandwidth(rthip_ctx* ctx, uint64_t bytes, uint32_t repeats, doubl
 
 /* Measurement aid: the rate at which the GPU's vector-memory pipelines serve the access shape of the
  * traversal when memory latency is out of the picture -- `active_lanes` scattered lanes of every
- * wave (1..64) each read the 16-byte pieces of a record of their own per step -- record_bytes = 64:
- * four pieces, as an inner-node step of trace_bvh (shader.wgsl:496-521) reads its sibling pair;
- * record_bytes = 128: eight, what a step of a 4-wide tree with exact boxes would read -- from a
- * table that stays in the L1, eight waves per SIMD, no dependence between steps.  Returns lane-loads
- * (16 bytes each) per second over the whole chip: the ceiling that the extend stage's own lane-loads
- * per second are quoted against on scenes that live in the caches, where HBM bandwidth does not
- * bind.  No counterpart upstream. */
-int rthip_gather_ceiling(rthip_ctx* ctx, uint32_t active_lanes, uint32_t record_bytes, double* lane_loads_per_s);
+ * wave (1..64) each read the 16-byte pieces of `records_in_flight` (1 or 2) records of their own per
+ * step -- record_bytes = 64: four pieces, as an inner-node step of trace_bvh (shader.wgsl:496-521)
+ * reads its sibling pair; record_bytes = 128: eight, what a step of a 4-wide tree with exact boxes
+ * would read -- from a table that stays in the L1, eight waves per SIMD, no dependence between
+ * steps.  Returns lane-loads (16 bytes each) per second over the whole chip.  The largest of the
+ * shapes is the ceiling that the extend stage's own lane-loads per second are quoted against on
+ * scenes that live in the caches, where HBM bandwidth does not bind.  No counterpart upstream. */
+int rthip_gather_ceiling(rthip_ctx* ctx, uint32_t active_lanes, uint32_t record_bytes, uint32_t records_in_flight, double* lane_loads_per_s);
 
 int rthip_synchronize(rthip_ctx* ctx);
 

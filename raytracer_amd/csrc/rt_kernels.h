@@ -45,12 +45,16 @@ __device__ __forceinline__ f3 xform_pos(f3 x, const float* m) {
 
 // unpack_rgba8 + sample_texture, shader.wgsl:144-160, 175-182.  The flat index follows the
 // reference arithmetic and is clamped to the texel array.
-__device__ __forceinline__ uint32_t fetch_texel(const SceneDev& sc, uint32_t offset, uint32_t size, float tcx, float tcy) {
+__device__ __forceinline__ uint64_t texel_index(const SceneDev& sc, uint32_t offset, uint32_t size, float tcx, float tcy) {
     const uint32_t w = size >> 16, h = size & 0xFFFFu;
     const uint32_t px = f2u(fractf(tcx) * (float)w);
     const uint32_t py = f2u(fractf(tcy) * (float)h);
     uint64_t idx = (uint64_t)(uint32_t)(offset + py * w + px);
     if (idx >= sc.n_texels) idx = sc.n_texels ? sc.n_texels - 1 : 0;
+    return idx;
+}
+__device__ __forceinline__ uint32_t fetch_texel(const SceneDev& sc, uint32_t offset, uint32_t size, float tcx, float tcy) {
+    const uint64_t idx = texel_index(sc, offset, size, tcx, tcy);
     return sc.n_texels ? sc.texels[idx] : 0u;
 }
 
@@ -249,6 +253,10 @@ typedef const __attribute__((address_space(4))) rt_float8* rt_cfloat8_p;
 typedef float rt_float3 __attribute__((ext_vector_type(3)));
 // the first 12 bytes of a 16-byte row
 __device__ __forceinline__ rt_float3 ld12(const float4* row) { return *reinterpret_cast<const rt_float3*>(row); }
+typedef float rt_float4 __attribute__((ext_vector_type(4)));
+typedef float rt_float2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rt_float4 ld16(const float4* row) { return *reinterpret_cast<const rt_float4*>(row); }
+__device__ __forceinline__ rt_float2 ld8(const float4* row) { return *reinterpret_cast<const rt_float2*>(row); }
 
 // Address of a record given its position in 16-byte units (one 64-bit shift-add; the record's
 // further 16-byte pieces are immediate offsets of the loads).  32 bits of units span 64 GiB.
@@ -1373,7 +1381,22 @@ __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* li
     // ---- handle_surface_hit_brdf, shader.wgsl:803-881
     if (COUNT) cnt.shade++;
     const PrimitiveD& pr = sc.prims[prim];
-    const float* im = pr.inv_transform;
+    // Everything the hit needs from the primitive, the triangle and its vertex attributes is
+    // read here, in one go, and the empty asm below is a fence for the scheduler: it wants all
+    // thirteen values in registers at this point, so the reads are issued back to back and waited
+    // for once.  Left alone, the compiler moves each read to its first use to save registers, and
+    // the hit becomes seven memory round trips in a row -- time that a kernel with four waves per
+    // SIMD (k_path) cannot hide.
+    const float4* icol = reinterpret_cast<const float4*>(pr.inv_transform); // column-major 4x4
+    const float4* trow = sc.tris + 3 * (size_t)tri;
+    const float4* ex = sc.exts + 6 * (size_t)tri;
+    rt_float3 ic0 = ld12(icol), ic1 = ld12(icol + 1), ic2 = ld12(icol + 2), ic3 = ld12(icol + 3);
+    rt_float3 tq0 = ld12(trow), tq1 = ld12(trow + 1), tq2 = ld12(trow + 2);
+    rt_float4 v0a = ld16(ex), v1a = ld16(ex + 2), v2a = ld16(ex + 4);
+    rt_float2 v0b = ld8(ex + 1), v1b = ld8(ex + 3), v2b = ld8(ex + 5);
+    asm volatile("" : "+v"(ic0), "+v"(ic1), "+v"(ic2), "+v"(ic3), "+v"(tq0), "+v"(tq1), "+v"(tq2),
+                      "+v"(v0a), "+v"(v1a), "+v"(v2a), "+v"(v0b), "+v"(v1b), "+v"(v2b));
+    const float im[15] = {ic0.x, ic0.y, ic0.z, 0.0f, ic1.x, ic1.y, ic1.z, 0.0f, ic2.x, ic2.y, ic2.z, 0.0f, ic3.x, ic3.y, ic3.z};
     // the primitive-space ray and the geometric normal, as trace() recomputes them
     // for the winning triangle (shader.wgsl:617-625, 376-412)
     const f3 td = F3((im[0] * dir.x + im[4] * dir.y) + im[8] * dir.z, (im[1] * dir.x + im[5] * dir.y) + im[9] * dir.z,
@@ -1382,8 +1405,7 @@ __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* li
     const f3 lo = F3(((im[0] * origin.x + im[4] * origin.y) + im[8] * origin.z) + im[12],
                      ((im[1] * origin.x + im[5] * origin.y) + im[9] * origin.z) + im[13],
                      ((im[2] * origin.x + im[6] * origin.y) + im[10] * origin.z) + im[14]);
-    const float4 a0 = sc.tris[3 * (size_t)tri], a1 = sc.tris[3 * (size_t)tri + 1], a2 = sc.tris[3 * (size_t)tri + 2];
-    const f3 p0 = F3(a0.x, a0.y, a0.z), e1 = F3(a1.x, a1.y, a1.z), e2 = F3(a2.x, a2.y, a2.z);
+    const f3 p0 = F3(tq0.x, tq0.y, tq0.z), e1 = F3(tq1.x, tq1.y, tq1.z), e2 = F3(tq2.x, tq2.y, tq2.z);
     f3 ng = normalize(cross(e1, e2));
     ng = ng * (-sign11(dot(ng, ld)));
     float bu = 0.333f, bv = 0.333f, b0 = 0.333f;
@@ -1400,8 +1422,6 @@ __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* li
     origin = origin + n_geo * 0.001f;
 
     // tri_ext_interpolate, shader.wgsl:229-253
-    const float4* ex = sc.exts + 6 * (size_t)tri;
-    const float4 v0a = ex[0], v0b = ex[1], v1a = ex[2], v1b = ex[3], v2a = ex[4], v2b = ex[5];
     float tc0x = 0.0f, tc0y = 0.0f, tc1x = 0.0f, tc1y = 0.0f;
     tc0x += b0 * v0a.x; tc0y += b0 * v0a.y; tc1x += b0 * v0a.z; tc1y += b0 * v0a.w;
     f3 sn = F3(0.0f, 0.0f, 0.0f) + unpack_oct(v0b.x, v0b.y) * b0;
@@ -1419,27 +1439,40 @@ __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* li
         sn = n_geo;
     }
 
+    // The three texture reads of a hit go out together and without a branch: every index is
+    // computed first (texel 0 for a texture that does not exist; its value is not used), then the
+    // reads are issued back to back, then their values are used.  Read one after the other, each
+    // behind its own branch, they were three memory round trips in a row, most of them misses of
+    // every cache (and a wait in one branch cannot leave the reads of the other branches in flight).
     const MaterialD& m = pr.material;
+    const uint32_t a_size = m.albedo.size, e_size = m.emissive.size, r_size = m.metallic_roughness.size;
+    const bool a_s1 = m.albedo_texcoord >= 1u, e_s1 = m.emissive_texcoord >= 1u, r_s1 = m.metal_r_texcoord >= 1u;
+    const uint64_t a_idx = texel_index(sc, m.albedo.offset, a_size, a_s1 ? tc1x : tc0x, a_s1 ? tc1y : tc0y);
+    const uint64_t e_idx = texel_index(sc, m.emissive.offset, e_size, e_s1 ? tc1x : tc0x, e_s1 ? tc1y : tc0y);
+    const uint64_t r_idx = texel_index(sc, m.metallic_roughness.offset, r_size, r_s1 ? tc1x : tc0x, r_s1 ? tc1y : tc0y);
+    uint32_t a_tex = 0u, e_tex = 0u, r_tex = 0u;
+    if (sc.n_texels) {
+        a_tex = sc.texels[a_size != 0u ? a_idx : 0ull];
+        e_tex = sc.texels[e_size != 0u ? e_idx : 0ull];
+        r_tex = sc.texels[r_size != 0u ? r_idx : 0ull];
+    }
     f3 albedo = F3(m.albedo_factor[0], m.albedo_factor[1], m.albedo_factor[2]);
-    if (m.albedo.size != 0u) {
-        const bool s1set = m.albedo_texcoord >= 1u;
+    if (a_size != 0u) {
         if (COUNT) cnt.texel++;
-        albedo = albedo * linear_rgb(lin_lut, fetch_texel(sc, m.albedo.offset, m.albedo.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+        albedo = albedo * linear_rgb(lin_lut, a_tex);
     } else {
         albedo = albedo * F3(0.01f, 0.02f, 0.03f);
     }
     f3 emissive = F3(m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2]);
-    if (m.emissive.size != 0u) {
-        const bool s1set = m.emissive_texcoord >= 1u;
+    if (e_size != 0u) {
         if (COUNT) cnt.texel++;
-        emissive = emissive * linear_rgb(lin_lut, fetch_texel(sc, m.emissive.offset, m.emissive.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+        emissive = emissive * linear_rgb(lin_lut, e_tex);
     }
     float metallic_chance = m.metallic_factor;
     float roughness = m.roughness_factor;
-    if (m.metallic_roughness.size != 0u) {
-        const bool s1set = m.metal_r_texcoord >= 1u;
+    if (r_size != 0u) {
         if (COUNT) cnt.texel++;
-        const f3 mr = unpack_rgb(fetch_texel(sc, m.metallic_roughness.offset, m.metallic_roughness.size, s1set ? tc1x : tc0x, s1set ? tc1y : tc0y));
+        const f3 mr = unpack_rgb(r_tex);
         metallic_chance = mr.z;
         roughness *= mr.y;
     }
@@ -1670,27 +1703,32 @@ __global__ __launch_bounds__(256) void k_unpack_hits(const float4* hits, uint32_
 
 // What a CU's vector-memory pipeline sustains for the access shape of the extend stage when memory
 // latency is out of the picture: every ACTIVE lane of a wave (lanes chosen by `mask`) reads the
-// 16-byte pieces of a record of its own per iteration -- four of a 64-byte record: the shape of an
-// inner-node step; or (WIDE) eight of a 128-byte record: what a step of a 4-wide tree with exact f32
-// boxes would read -- from a 16 KiB table that stays in the L1; the loads of an iteration do not
-// depend on each other and eight waves share a SIMD, so the time is the throughput of the address /
-// tag / return path, not a latency.  The record a lane reads changes every iteration (a small LCG),
-// as the nodes of a traversal do.
-template <bool WIDE>
+// 16-byte pieces of RECS records of its own per iteration -- PIECES = 4 of a 64-byte record: the
+// shape of an inner-node step; PIECES = 8 of a 128-byte record: what a step of a 4-wide tree with
+// exact f32 boxes would read; RECS = 2: two records, i.e. twice the loads in flight per wave -- from a
+// 16 KiB table that stays in the L1; the loads of an iteration do not depend on each other and eight
+// waves share a SIMD, so the time is the throughput of the address / tag / return path, not a
+// latency.  The records a lane reads change every iteration (a small LCG), as the nodes of a
+// traversal do.
+template <uint32_t PIECES, uint32_t RECS>
 __global__ __launch_bounds__(256, 8) void k_gather_ceiling(const float4* table, unsigned long long mask, uint32_t iters, float* sink) {
-    constexpr uint32_t PIECES = WIDE ? 8u : 4u;         // float4 per record
     constexpr uint32_t RECORDS = 16384u / (16u * PIECES);
     const uint32_t lane = lane_id();
     float acc = 0.0f;
     if ((mask >> lane) & 1ull) {
         uint32_t idx = (threadIdx.x * 7u + blockIdx.x * 13u) & (RECORDS - 1u);
         for (uint32_t i = 0; i < iters; i++) {
-            const float4* r = table + idx * PIECES;
-            const float4 a = r[0], b = r[1], c = r[2], d = r[3];
-            acc += (a.x + b.y) + (c.z + d.w);
-            if (WIDE) {
-                const float4 e = r[4], f = r[5], g = r[6], h = r[7];
-                acc += (e.x + f.y) + (g.z + h.w);
+            float4 v[RECS][PIECES];
+#pragma unroll
+            for (uint32_t r = 0; r < RECS; r++) {
+                const float4* rec = table + ((idx + r * (RECORDS / 2u + 3u)) & (RECORDS - 1u)) * PIECES;
+#pragma unroll
+                for (uint32_t k = 0; k < PIECES; k++) v[r][k] = rec[k];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < RECS; r++) {
+#pragma unroll
+                for (uint32_t k = 0; k < PIECES; k += 4u) acc += (v[r][k].x + v[r][k + 1u].y) + (v[r][k + 2u].z + v[r][k + 3u].w);
             }
             idx = (idx * 5u + 1u) & (RECORDS - 1u);
         }

@@ -1811,11 +1811,12 @@ int rthip_copy_bandwidth(rthip_ctx* c, uint64_t bytes, uint32_t repeats, double*
     return RTHIP_OK;
 }
 
-int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, uint32_t record_bytes, double* lane_loads_per_s) {
+int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, uint32_t record_bytes, uint32_t records_in_flight, double* lane_loads_per_s) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     if (!lane_loads_per_s || active_lanes == 0 || active_lanes > 64) return fail(c, RTHIP_ERR_INVALID, "gather_ceiling: null result, or active_lanes outside 1..64");
     if (record_bytes != 64 && record_bytes != 128) return fail(c, RTHIP_ERR_INVALID, "gather_ceiling: record_bytes %u is neither 64 nor 128", record_bytes);
-    const bool wide = record_bytes == 128;
+    if (records_in_flight != 1 && records_in_flight != 2) return fail(c, RTHIP_ERR_INVALID, "gather_ceiling: records_in_flight %u is neither 1 nor 2", records_in_flight);
+    const bool wide = record_bytes == 128, two = records_in_flight == 2;
     DeviceGuard g(c->device);
     // `active_lanes` lanes spread over the wave by a fixed permutation (scattered, as the lanes that
     // share a step kind are)
@@ -1830,15 +1831,19 @@ int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, uint32_t record_by
     if (e == hipSuccess) e = hipMemsetAsync(table, 0, 256 * 64, c->stream);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
+    auto launch = [&](uint32_t n) {
+        const float4* t = (const float4*)table;
+        if (wide && two) hipLaunchKernelGGL((k_gather_ceiling<8u, 2u>), dim3(blocks), dim3(256), 0, c->stream, t, mask, n, sink);
+        else if (wide) hipLaunchKernelGGL((k_gather_ceiling<8u, 1u>), dim3(blocks), dim3(256), 0, c->stream, t, mask, n, sink);
+        else if (two) hipLaunchKernelGGL((k_gather_ceiling<4u, 2u>), dim3(blocks), dim3(256), 0, c->stream, t, mask, n, sink);
+        else hipLaunchKernelGGL((k_gather_ceiling<4u, 1u>), dim3(blocks), dim3(256), 0, c->stream, t, mask, n, sink);
+    };
     if (e == hipSuccess) {
-        // untimed first: code and table in the caches
-        if (wide) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, 50u, sink);
-        else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, 50u, sink);
+        launch(50u); // untimed first: code and table in the caches
         e = hipEventRecord(e0, c->stream);
     }
     if (e == hipSuccess) {
-        if (wide) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, iters, sink);
-        else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3(blocks), dim3(256), 0, c->stream, (const float4*)table, mask, iters, sink);
+        launch(iters);
         e = hipEventRecord(e1, c->stream);
     }
     if (e == hipSuccess) e = hipEventSynchronize(e1);
@@ -1850,8 +1855,8 @@ int rthip_gather_ceiling(rthip_ctx* c, uint32_t active_lanes, uint32_t record_by
     if (table) (void)hipFree(table);
     if (sink) (void)hipFree(sink);
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "gather_ceiling: %s", hipGetErrorString(e));
-    // blocks x 4 waves x iters iterations x 4 (or 8) loads, each by active_lanes lanes
-    *lane_loads_per_s = ms > 0.0f ? (double)blocks * 4.0 * iters * (wide ? 8.0 : 4.0) * active_lanes / ((double)ms * 1e-3) : 0.0;
+    // blocks x 4 waves x iters iterations x (4 or 8 loads) x (1 or 2 records), each by active_lanes lanes
+    *lane_loads_per_s = ms > 0.0f ? (double)blocks * 4.0 * iters * (wide ? 8.0 : 4.0) * (two ? 2.0 : 1.0) * active_lanes / ((double)ms * 1e-3) : 0.0;
     return RTHIP_OK;
 }
 

@@ -94,7 +94,7 @@ def lib():
         l.rthip_trace_rays.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_trace_rays_noalloc.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(RenderParams), vp, vp, vp, vp]
         l.rthip_copy_bandwidth.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
-        l.rthip_gather_ceiling.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        l.rthip_gather_ceiling.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         l.rthip_default_params.restype = None
         l.rthip_render.argtypes = [vp, u32, u32, u32, C.POINTER(RenderParams)]
         l.rthip_bind_accum.argtypes = [vp, vp, u64]
@@ -242,12 +242,12 @@ class Context:
         self._check(lib().rthip_copy_bandwidth(self._h, int(nbytes), int(repeats), C.byref(out)))
         return float(out.value)
 
-    def gather_ceiling(self, active_lanes, record_bytes=64):
+    def gather_ceiling(self, active_lanes, record_bytes=64, records_in_flight=1):
         """Lane-loads (16 bytes each) per second that the chip's vector-memory pipelines serve out of
-        the L1 for `active_lanes` scattered lanes per wave reading a record of 64 bytes (the inner-node
-        step's shape) or 128 bytes each per step."""
+        the L1 for `active_lanes` scattered lanes per wave reading one or two records of 64 bytes (the
+        inner-node step's shape) or 128 bytes each per step."""
         out = C.c_double()
-        self._check(lib().rthip_gather_ceiling(self._h, int(active_lanes), int(record_bytes), C.byref(out)))
+        self._check(lib().rthip_gather_ceiling(self._h, int(active_lanes), int(record_bytes), int(records_in_flight), C.byref(out)))
         return float(out.value)
 
     def synchronize(self):

@@ -97,7 +97,7 @@ extern "C" {
     pub fn rthip_candidate_walk(ctx: *mut rthip_ctx, kind: *mut u32) -> c_int;
     pub fn rthip_copy_bandwidth(ctx: *mut rthip_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;
     /// Lane-loads per second of the traversal's access shape out of the L1 (a measured ceiling).
-    pub fn rthip_gather_ceiling(ctx: *mut rthip_ctx, active_lanes: u32, record_bytes: u32, lane_loads_per_s: *mut f64) -> c_int;
+    pub fn rthip_gather_ceiling(ctx: *mut rthip_ctx, active_lanes: u32, record_bytes: u32, records_in_flight: u32, lane_loads_per_s: *mut f64) -> c_int;
     pub fn rthip_bind_accum(ctx: *mut rthip_ctx, device_ptr: *mut c_void, n_pixels: u64) -> c_int;
     pub fn rthip_accum_device_ptr(ctx: *mut rthip_ctx, device_ptr: *mut *mut c_void, n_pixels: *mut u64) -> c_int;
     pub fn rthip_read_accum(ctx: *mut rthip_ctx, rgba: *mut f32, n_pixels: u64) -> c_int;
