@@ -66,7 +66,7 @@ typedef struct {
 #define RTHIP_FLAG_COUNTERS 1u   /* maintain rthip_counters (small cost)                       */
 #define RTHIP_FLAG_TAPS     2u   /* record primary hits + final seeds of the first frame       */
 #define RTHIP_FLAG_TIMING   4u   /* bracket every stage launch with HIP events (rthip_timing)  */
-#define RTHIP_FLAG_STAGED   8u   /* calls of one to three frames too go through the staged pipeline
+#define RTHIP_FLAG_STAGED   8u   /* small frame groups (up to 5 * 2^20 camera paths) too go through the staged pipeline
                                     (generate / cull / extend / shade launches per bounce) instead of
                                     the single launch in which a lane owns a whole path; the result
                                     is the same bit for bit                                       */
@@ -102,7 +102,7 @@ typedef struct {
 #define RTHIP_STAGE_ACCUMULATE 4 /* frame-ordered sum of the per-frame results into screen  */
 #define RTHIP_STAGE_SHADOW   5   /* enable_sun only: the shadow rays of a bounce             */
 #define RTHIP_STAGE_CULL     6   /* candidate primitives per ray (scenes of up to 128 primitives) */
-#define RTHIP_STAGE_PATH     7   /* calls of one to three frames: the whole of cs_main in one launch */
+#define RTHIP_STAGE_PATH     7   /* small frame groups: the whole of cs_main in one launch */
 #define RTHIP_NUM_STAGES     8
 
 typedef struct {

@@ -1333,7 +1333,7 @@ __device__ __forceinline__ f3 linear_rgb(const float* lut, uint32_t x) {
 #define RT_PATH_SHADOW 2   // SUN only: origin, dir are the shadow ray, sun_term what it carries, lit the light gathered so far
 struct ShadeCounts { unsigned long long shade = 0, miss = 0, kill = 0, texel = 0; };
 
-template <bool COUNT, bool SUN>
+template <bool COUNT, bool SUN, bool TOGETHER = true>
 __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* lin_lut, float term_prob, f3& origin, f3& dir, f3& thr, f3& lit,
                                              uint32_t& seed, int32_t tri, uint32_t prim, float hit_t, f3& sun_term, ShadeCounts& cnt) {
     if (tri < 0) { // handle_miss / sky / sample_env_map, shader.wgsl:883-885, 691-702
@@ -1382,11 +1382,12 @@ __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* li
     if (COUNT) cnt.shade++;
     const PrimitiveD& pr = sc.prims[prim];
     // Everything the hit needs from the primitive, the triangle and its vertex attributes is
-    // read here, in one go, and the empty asm below is a fence for the scheduler: it wants all
-    // thirteen values in registers at this point, so the reads are issued back to back and waited
-    // for once.  Left alone, the compiler moves each read to its first use to save registers, and
-    // the hit becomes seven memory round trips in a row -- time that a kernel with four waves per
-    // SIMD (k_path) cannot hide.
+    // read here, in one go, and (TOGETHER) the empty asm below is a fence for the scheduler: it
+    // wants all thirteen values in registers at this point, so the reads are issued back to back
+    // and waited for once.  Left alone, the compiler moves each read to its first use to save
+    // registers, and the hit becomes seven memory round trips in a row.  Worth 5 % of the shade
+    // stage; k_path, which has no register to spare (the fence costs it a spilled one) and gains
+    // nothing measurable, calls without.
     const float4* icol = reinterpret_cast<const float4*>(pr.inv_transform); // column-major 4x4
     const float4* trow = sc.tris + 3 * (size_t)tri;
     const float4* ex = sc.exts + 6 * (size_t)tri;
@@ -1394,8 +1395,9 @@ __device__ __forceinline__ int shade_segment(const SceneDev& sc, const float* li
     rt_float3 tq0 = ld12(trow), tq1 = ld12(trow + 1), tq2 = ld12(trow + 2);
     rt_float4 v0a = ld16(ex), v1a = ld16(ex + 2), v2a = ld16(ex + 4);
     rt_float2 v0b = ld8(ex + 1), v1b = ld8(ex + 3), v2b = ld8(ex + 5);
-    asm volatile("" : "+v"(ic0), "+v"(ic1), "+v"(ic2), "+v"(ic3), "+v"(tq0), "+v"(tq1), "+v"(tq2),
-                      "+v"(v0a), "+v"(v1a), "+v"(v2a), "+v"(v0b), "+v"(v1b), "+v"(v2b));
+    if (TOGETHER)
+        asm volatile("" : "+v"(ic0), "+v"(ic1), "+v"(ic2), "+v"(ic3), "+v"(tq0), "+v"(tq1), "+v"(tq2),
+                          "+v"(v0a), "+v"(v1a), "+v"(v2a), "+v"(v0b), "+v"(v1b), "+v"(v2b));
     const float im[15] = {ic0.x, ic0.y, ic0.z, 0.0f, ic1.x, ic1.y, ic1.z, 0.0f, ic2.x, ic2.y, ic2.z, 0.0f, ic3.x, ic3.y, ic3.z};
     // the primitive-space ray and the geometric normal, as trace() recomputes them
     // for the winning triangle (shader.wgsl:617-625, 376-412)

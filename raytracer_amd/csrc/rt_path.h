@@ -1,7 +1,7 @@
-// The whole of cs_main (shader.wgsl:886-953) for calls of a few frames, in ONE persistent launch.
+// The whole of cs_main (shader.wgsl:886-953) for small frame groups, in ONE persistent launch.
 //
 // A host that shows every sample (the reference's frame(), main.rs:356-407: one dispatch per
-// redraw) hands over one to three frames per call.  The staged pipeline of rt_kernels.h then spends
+// redraw) hands over one frame per call, or a few.  The staged pipeline of rt_kernels.h then spends
 // most of the call in the tails of its per-bounce launches: a persistent launch ends when its
 // slowest wave does, and one frame has thirteen launches.  Here a lane owns a PATH instead of a
 // ray: it makes the camera ray itself (camera_path, the generate stage's code), walks it through
@@ -14,8 +14,10 @@
 // operand order), so its result is bit-identical; paths only finish in another order, which no
 // result depends on (one writer per accumulation slot, frames summed in frame order afterwards).
 //
-// Scenes of up to 128 primitives (one chunk of candidates) and traversal stacks that fit the LDS
-// column; everything else keeps the staged pipeline.
+// Frame groups of at most RT_PATH_MAX_SLOTS camera paths (two 1080p frames; any group of a small
+// image), scenes of up to 128 primitives (one chunk of candidates) and traversal stacks that fit
+// the LDS column; everything else keeps the staged pipeline, which is the faster one once its
+// launches are long.
 #pragma once
 
 #include "rt_kernels.h"
@@ -26,7 +28,14 @@
 #ifndef RT_PATH_WAVES
 #define RT_PATH_WAVES 4
 #endif
-#define RT_PATH_MAX_FRAMES 3u     // frames per call up to which a call runs this way
+#ifndef RT_PATH_MAX_SLOTS
+// A frame group runs this way if it has at most this many camera paths (whatever its number of
+// frames): beyond, the staged pipeline's tails weigh less than this kernel's lower rate.  This
+// kernel's time over the staged pipeline's, 1080p atrium: 512x512 x 1 / 4 / 16 frames 0.61 / 0.69 /
+// 0.89; 720p x 1 / 3 / 5: 0.65 / 0.77 / 0.94; 1080p x 1 / 2 / 3: 0.79 / 0.94 / 1.06; 1440p x 1 / 2:
+// 0.92 / 1.11; 4K x 1: 1.11.
+#define RT_PATH_MAX_SLOTS (5u << 20)
+#endif
 #ifndef RT_PATH_LDS_LEVELS
 #define RT_PATH_LDS_LEVELS 23u   // the reference's stack depth (shader.wgsl:303)
 #endif
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                 f3 thr = F3(pth[0], pth[256], pth[512]), lit = F3(pth[768], pth[1024], pth[1280]);
                 const bool overflow = (hit_prim >> 31) != 0u;
                 f3 sun_term;
-                int what = shade_segment<COUNT, false>(sc, lin_lut, a.term_prob, origin, dir, thr, lit, seed, hit_i, hit_prim & 0x7FFFFFFFu,
+                int what = shade_segment<COUNT, false, false>(sc, lin_lut, a.term_prob, origin, dir, thr, lit, seed, hit_i, hit_prim & 0x7FFFFFFFu,
                                                        closest_t, sun_term, cnt);
                 if (what == RT_PATH_BOUNCE && bounce + 1u == a.max_bounces) what = RT_PATH_END; // loop bound, shader.wgsl:898
                 if (what == RT_PATH_BOUNCE) {

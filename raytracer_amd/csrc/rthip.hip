@@ -1072,7 +1072,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     if (const char* e = knob(c, "RTHIP_SPREAD")) spread_env = std::atoi(e);
     int path_blocks_env = 0;
     if (const char* e = knob(c, "RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
-    const bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
+    bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
+    if (const char* e = knob(c, "RTHIP_FORCE_STAGED")) staged_only = staged_only || std::atoi(e) != 0; // tests: a whole module through the staged pipeline
     int lpt_env = 1;
     if (const char* e = knob(c, "RTHIP_PATH_LONGEST_FIRST")) lpt_env = std::atoi(e); // experiment knob: 0 = runs as they come
 
@@ -1148,7 +1149,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         // (rt_path.h): the staged pipeline below would spend most of such a call in the tails of its
         // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk and
         // stacks that fit the LDS column only.
-        const bool fused = !staged_only && nf <= RT_PATH_MAX_FRAMES && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun &&
+        const bool fused = !staged_only && slots <= RT_PATH_MAX_SLOTS && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun &&
                            c->watchdog_dev != nullptr;
         if (fused) {
             PathArgs pa{};

@@ -35,7 +35,7 @@ def make_case(rng):
     p = device.default_params(max_bounces=int(rng.integers(1, 9)), term_prob=float(rng.choice([0.5, 0.5, 0.25, 0.8])),
                               stack_depth=int(rng.choice([1, 3, 8, 13, 14, 23, 23, 40, 64])), enable_sun=int(rng.integers(0, 2)))
     first, n = int(rng.integers(1, 1000)), int(rng.integers(1, 5))
-    staged = bool(rng.integers(0, 3) == 0)   # a third of the calls of one to three frames are sent through the staged pipeline
+    staged = bool(rng.integers(0, 3) == 0)   # a third of the calls are sent through the staged pipeline (the others run as one launch: small images)
     return dict(kind=kind, walk=walk, scene=s, res=res, params=p, first=first, n=n, staged=staged)
 
 

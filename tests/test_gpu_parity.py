@@ -13,6 +13,15 @@ from util import oracle_params, oracle_scene, psnr, tonemapped
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["default", "staged"])
+def pipeline(request, monkeypatch):
+    """Every test of this module runs twice: as the library chooses (small frame groups = one
+    persistent launch, k_path) and with every group forced through the staged pipeline."""
+    if request.param == "staged":
+        monkeypatch.setenv("RTHIP_FORCE_STAGED", "1")
+    return request.param
+
 SCENES = {
     "box": (procedural.box_scene, dict(env_size=(128, 64))),
     "blob": (procedural.blob_scene, dict(env_size=(256, 128))),

@@ -18,6 +18,15 @@ from util import GOLDEN, load_reference_scene, oracle_params, oracle_scene, psnr
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["default", "staged"])
+def pipeline(request, monkeypatch):
+    """Every test of this module runs twice: as the library chooses (small frame groups = one
+    persistent launch, k_path) and with every group forced through the staged pipeline."""
+    if request.param == "staged":
+        monkeypatch.setenv("RTHIP_FORCE_STAGED", "1")
+    return request.param
+
 THREADS = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
 
 

@@ -1,6 +1,6 @@
-"""Calls of one to three frames run as one persistent launch in which a lane owns a whole path
-(k_path); longer calls, and calls with RTHIP_FLAG_STAGED, go through the staged pipeline (generate /
-cull / extend / shade per bounce).  Both run the same code per path, so everything they produce must
+"""Frame groups of at most 5 * 2^20 camera paths (two 1080p frames; any group of a small image) run
+as one persistent launch in which a lane owns a whole path (k_path); larger ones, and calls with
+RTHIP_FLAG_STAGED, go through the staged pipeline (generate / cull / extend / shade per bounce).  Both run the same code per path, so everything they produce must
 be equal bit for bit -- accumulators, primary-hit taps, final RNG states, traversal counters -- and
 the short path must stand against the oracle on its own.
 """
@@ -81,18 +81,30 @@ def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name):
 
 
 def test_short_path_is_the_one_that_runs(ctx, scenes):
-    """Timing records which launches a call made: one to three frames = one k_path launch and no
-    stage launch; four frames = the staged pipeline."""
+    """Timing records which launches a call made: a frame group of at most 5 * 2^20 camera paths =
+    one k_path launch and no stage launch (15 360 per frame here: any group); more = the staged
+    pipeline (a 1080p frame has 2 073 600: two frames run as one launch, three are staged)."""
     s, a, res = scenes["materials"]
     ctx.upload_scene(a)
     ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
     p = device.default_params(flags=device.FLAG_TIMING)
-    for n, want_path in ((1, 1), (2, 1), (3, 1), (4, 0)):
+    for n in (1, 2, 3, 4, 64):
+        ctx.reset_timing()
+        ctx.render(1, n, 1, p)
+        t = ctx.timing()
+        assert t["path"]["launches"] == 1, (n, t)
+        assert t["extend"]["launches"] == 0, (n, t)
+    ctx.reset_timing()
+    ctx.render(1, 65, 1, p)          # two frame groups (64 frames in flight): two launches
+    assert ctx.timing()["path"]["launches"] == 2
+    ctx.set_frame_uniforms(s.frame_uniforms((1920, 1080), frame=1, reject_hist=1))
+    for n, want_path in ((2, 1), (3, 0)):
         ctx.reset_timing()
         ctx.render(1, n, 1, p)
         t = ctx.timing()
         assert t["path"]["launches"] == want_path, (n, t)
         assert (t["extend"]["launches"] == 0) == (want_path == 1), (n, t)
+    ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
     # a stack deeper than the short path's LDS column, and the sun option, keep the staged pipeline
     for kw in (dict(stack_depth=40), dict(enable_sun=1)):
         ctx.reset_timing()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: the shape of the single launch that renders a call of one to three frames (k_path).
+"""Diagnostic: the shape of the single launch that renders a small frame group (k_path).
 Needs a probe build of the device library (bash tools/build_variant.sh probe -DRT_PROBE [knobs]):
 every wave records when it started, when it found no camera path left and when it ended, its
 rounds by kind and the lanes that had traversal work in them.

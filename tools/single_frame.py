@@ -3,7 +3,7 @@
 time: wall time per call and HIP-event time per stage, for the headline workload.
     python tools/single_frame.py [--frames 1] [--calls 20] [--staged] [bench.py workload arguments]
 --staged sends the call through the staged pipeline (RTHIP_FLAG_STAGED) instead of the single launch
-that calls of one to three frames get."""
+that small frame groups get."""
 import json
 import os
 import sys
