@@ -601,6 +601,18 @@ def main():
                 ctx.render(args.first_frame + 3 + n_single + f, 1, 1, p_bare)
                 ctx.resolve()
             out["ms_per_frame_single_with_resolve_to_host"] = round((time.perf_counter() - t0) / n_single * 1e3, 4)
+            # ... and with the image left on the device, where the reference's render pass leaves it (main.rs:395-401)
+            # (device memory straight from the HIP runtime the library has loaded: importing torch after it brings a second runtime)
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            shown = ctypes.c_void_p()
+            if hip.hipMalloc(ctypes.byref(shown), ctypes.c_size_t(res[0] * res[1] * 4)) == 0:
+                t0 = time.perf_counter()
+                for f in range(n_single):
+                    ctx.render(args.first_frame + 3 + 2 * n_single + f, 1, 1, p_bare)
+                    ctx.resolve_into(shown.value)
+                out["ms_per_frame_single_with_resolve_on_device"] = round((time.perf_counter() - t0) / n_single * 1e3, 4)
+                hip.hipFree(shown)
         if args.random_rays > 0 and mode == "single":
             out["random_rays"] = random_rays_bench(ctx, arrays, args.random_rays, p_plain, device)
         if mode == "single" and not args.no_cpu_baseline:

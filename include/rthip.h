@@ -227,7 +227,10 @@ int rthip_trace_rays_noalloc(rthip_ctx* ctx, const float* d_rays6, uint32_t* d_s
 
 /* The render pass of frame() (main.rs:395-401; fs_main, shader.wgsl:994-1012): mean, PBR
  * Neutral tonemap, then the linear->sRGB transfer the reference gets from its sRGB surface
- * (main.rs:116) when apply_srgb_oetf != 0, rounded to 8 bits; alpha = 255. */
+ * (main.rs:116) when apply_srgb_oetf != 0, rounded to 8 bits; alpha = 255.  `rgba8` is host
+ * memory (pageable or pinned: the image is copied there) or 4-byte-aligned memory of the context's
+ * GPU (a presentation buffer: the kernel writes it in place, no copy and no allocation).
+ * Returns when the image is there. */
 int rthip_resolve(rthip_ctx* ctx, uint8_t* rgba8, uint64_t n_pixels, int apply_srgb_oetf);
 
 int rthip_get_counters(rthip_ctx* ctx, rthip_counters* out);

@@ -1726,17 +1726,27 @@ int rthip_resolve(rthip_ctx* c, uint8_t* rgba8, uint64_t n_pixels, int apply_srg
         int rc = ensure_accum(c);
         if (rc != RTHIP_OK) return rc;
     }
-    if (c->resolve_cap < n_pixels) {
+    // The output may be memory of this GPU (a presentation buffer: what the reference's render pass
+    // writes, main.rs:395-401): the image is then written there by the kernel, nothing is copied
+    // and nothing allocated.  Anything else (pageable or pinned host memory) gets a copy.
+    bool on_device = false;
+    {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, rgba8) == hipSuccess) on_device = at.type == hipMemoryTypeDevice && at.device == c->device && (reinterpret_cast<uintptr_t>(rgba8) & 3u) == 0;
+        else (void)hipGetLastError(); // an ordinary host pointer the runtime has never seen
+    }
+    if (!on_device && c->resolve_cap < n_pixels) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         free_dev_t(c->resolve_out);
         c->resolve_cap = 0;
         HIP_TRY(c, hipMalloc((void**)&c->resolve_out, 4 * n_pixels));
         c->resolve_cap = n_pixels;
     }
-    uint32_t* const d_out = c->resolve_out;
+    uint32_t* const d_out = on_device ? reinterpret_cast<uint32_t*>(rgba8) : c->resolve_out;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 8, (n_pixels + 255) / 256);
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, c->stream, (const float4*)c->accum, d_out, n_pixels, apply_srgb_oetf);
-    hipError_t e = hipMemcpyAsync(rgba8, d_out, 4 * n_pixels, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipSuccess;
+    if (!on_device) e = hipMemcpyAsync(rgba8, d_out, 4 * n_pixels, hipMemcpyDefault, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, RTHIP_ERR_HIP, "resolve: %s", hipGetErrorString(e));
     return check_watchdog(c);

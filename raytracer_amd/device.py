@@ -313,6 +313,12 @@ class Context:
         self._check(lib().rthip_resolve(self._h, _p(out), w * h, 1 if apply_srgb_oetf else 0))
         return out
 
+    def resolve_into(self, ptr, apply_srgb_oetf=True):
+        """The image into memory the caller names by address: host memory, or memory of this GPU
+        (w * h * 4 bytes, 4-byte aligned), which the kernel then writes in place."""
+        w, h = self.res
+        self._check(lib().rthip_resolve(self._h, C.c_void_p(int(ptr)), w * h, 1 if apply_srgb_oetf else 0))
+
     def counters(self):
         c = CountersStruct()
         self._check(lib().rthip_get_counters(self._h, C.byref(c)))

@@ -379,3 +379,32 @@ def test_resize_without_a_render_gives_an_empty_image_not_the_old_buffer():
         assert not c.read_accum().any()
     finally:
         c.close()
+
+
+def test_resolve_into_device_or_pinned_memory_equals_resolve_to_host():
+    """rthip_resolve writes the image in place when it is handed memory of its own GPU (the
+    presentation buffer of the reference's render pass, main.rs:395-401, lives on the device),
+    copies it to pinned host memory like to any other, and allocates nothing in the first case."""
+    import torch
+    s = procedural.material_test_scene(tex=32, env_size=(64, 32))
+    c = device.Context(0)
+    try:
+        c.upload_scene(s.arrays())
+        res = (97, 41)
+        c.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
+        c.render(1, 4, 1, device.default_params())
+        on_dev = torch.zeros(res[0] * res[1] * 4 + 8, dtype=torch.uint8, device="cuda:0")
+        pinned = torch.zeros(res[0] * res[1] * 4, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        c.resolve_into(on_dev.data_ptr())          # before any resolve to the host: no staging image exists yet
+        assert torch.cuda.mem_get_info()[0] == free0
+        want = c.resolve()
+        got = on_dev.cpu().numpy()
+        assert np.array_equal(got[:-8].reshape(res[1], res[0], 4), want) and not got[-8:].any()
+        c.resolve_into(pinned.data_ptr())
+        assert np.array_equal(pinned.numpy().reshape(res[1], res[0], 4), want)
+        c.resolve_into(on_dev.data_ptr(), apply_srgb_oetf=False)
+        assert np.array_equal(on_dev.cpu().numpy()[:-8].reshape(res[1], res[0], 4), c.resolve(apply_srgb_oetf=False))
+    finally:
+        c.close()
