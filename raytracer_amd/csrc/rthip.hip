@@ -1149,7 +1149,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         // (rt_path.h): the staged pipeline below would spend most of such a call in the tails of its
         // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk and
         // stacks that fit the LDS column only.
-        const bool fused = !staged_only && slots <= RT_PATH_MAX_SLOTS && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun &&
+        // (the bound was measured on 256 CUs; a partition of the chip gets its share of it)
+        const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun &&
                            c->watchdog_dev != nullptr;
         if (fused) {
             PathArgs pa{};
