@@ -547,35 +547,81 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
 // paths that start late through foliage keep a few waves busy long after the others have gone; the
 // same paths started first are over while there is still work for everybody.  Whatever the costs
 // are, `order` comes out a permutation of 0 .. n_runs - 1 (a counting sort over 256 cost levels:
-// every run gets exactly one place), and the result of a render does not depend on it.  One block;
-// also clears the costs for the next call.
+// every run gets exactly one place, whatever level the float arithmetic assigns it, because both
+// passes compute the level the same way), and the result of a render does not depend on it.  One
+// block; also clears the costs for the next call.
 __global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
-    __shared__ uint32_t bucket[256];
+    // a histogram per wave: most runs fall into a few dozen cost levels, and 1024 threads counting
+    // into one set of 256 LDS words spend their time queueing for the same words
+    __shared__ uint32_t bucket[16][256];
     __shared__ uint32_t red[1024];
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, w = t >> 6;
+    // (every pass reads eight costs per thread at a time: the reads of a plain loop wait for each other)
     uint32_t mx = 0;
-    for (uint32_t i = t; i < n_runs; i += 1024u) mx = max(mx, cost[i]);
+    for (uint32_t base = t; base < n_runs; base += 8192u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) { const uint32_t i = base + k * 1024u; v[k] = i < n_runs ? cost[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) mx = max(mx, v[k]);
+    }
     red[t] = mx;
-    if (t < 256u) bucket[t] = 0u;
+    for (uint32_t k = t; k < 16u * 256u; k += 1024u) (&bucket[0][0])[k] = 0u;
     __syncthreads();
-    for (uint32_t w = 512u; w > 0u; w >>= 1) {
-        if (t < w) red[t] = max(red[t], red[t + w]);
+    for (uint32_t h = 512u; h > 0u; h >>= 1) {
+        if (t < h) red[t] = max(red[t], red[t + h]);
         __syncthreads();
     }
     const uint32_t top = red[0];
     // level 0 = the most expensive
-    auto level = [&](uint32_t c) -> uint32_t { return top == 0u ? 0u : 255u - (uint32_t)(((unsigned long long)c * 255ull) / top); };
-    for (uint32_t i = t; i < n_runs; i += 1024u) atomicAdd(&bucket[level(cost[i])], 1u);
-    __syncthreads();
-    if (t == 0u) { // exclusive prefix over the 256 levels
-        uint32_t acc = 0u;
-        for (uint32_t b = 0; b < 256u; b++) { const uint32_t c = bucket[b]; bucket[b] = acc; acc += c; }
+    const float to_level = top == 0u ? 0.0f : 255.0f / (float)top;
+    auto level = [&](uint32_t c) -> uint32_t { return 255u - min(255u, (uint32_t)((float)c * to_level)); };
+    for (uint32_t base = t; base < n_runs; base += 8192u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) { const uint32_t i = base + k * 1024u; v[k] = i < n_runs ? cost[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) if (base + k * 1024u < n_runs) atomicAdd(&bucket[w][level(v[k])], 1u);
     }
     __syncthreads();
-    for (uint32_t i = t; i < n_runs; i += 1024u) {
-        const uint32_t c = cost[i];
-        order[atomicAdd(&bucket[level(c)], 1u)] = i;
-        cost[i] = 0u;
+    // exclusive prefix over (level, wave): level-major, so that the order is by level
+    if (t < 256u) {
+        uint32_t sum = 0u;
+        for (uint32_t k = 0; k < 16u; k++) { const uint32_t c = bucket[k][t]; bucket[k][t] = sum; sum += c; }
+        red[t] = sum; // runs at level t
+    }
+    __syncthreads();
+    // exclusive prefix over the 256 levels: a scan inside each of the first four waves, then their totals
+    uint32_t mine = 0u, incl = 0u;
+    if (t < 256u) {
+        mine = red[t];
+        incl = mine;
+        for (uint32_t o = 1u; o < 64u; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((t & 63u) >= o) incl += up;
+        }
+        if ((t & 63u) == 63u) red[256u + w] = incl;
+    }
+    __syncthreads();
+    if (t < 256u) {
+        uint32_t before = 0u;
+        for (uint32_t k = 0; k < w; k++) before += red[256u + k];
+        red[t] = before + incl - mine;
+    }
+    __syncthreads();
+    for (uint32_t base = t; base < n_runs; base += 8192u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) { const uint32_t i = base + k * 1024u; v[k] = i < n_runs ? cost[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t i = base + k * 1024u;
+            if (i < n_runs) {
+                const uint32_t l = level(v[k]);
+                order[red[l] + atomicAdd(&bucket[w][l], 1u)] = i;
+                cost[i] = 0u;
+            }
+        }
     }
 }
 
