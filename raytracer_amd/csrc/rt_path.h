@@ -94,7 +94,13 @@ struct PathArgs {
 #endif
 };
 
-template <bool COUNT>
+// SUN: the sun option (shader.wgsl:916-937).  A path that the termination draw ends sends one shadow
+// ray towards the sun; here the lane walks it like any other ray of its path, in "shadow mode" (top
+// bit of `bounce`): no distance bound, no alpha test, over at the first triangle it meets
+// (trace_bvh_shadow, shader.wgsl:528-575), not counted by the traversal counters -- what the
+// ANYHIT instantiation of k_extend does -- and the path round after it is the path's end.
+#define RT_PATH_SHADOW_BIT 0x80000000u
+template <bool COUNT, bool SUN>
 __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     __shared__ uint32_t lds_stack[4 * RT_PATH_LDS_LEVELS * RT_WAVE];
     __shared__ float lds_ray[6 * 256];   // world-space origin and direction of the lane's current ray
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     const SceneDev& sc = a.sc;
     const void* const nodes = sc.nodes;
     const void* const tris = sc.tris;
-    unsigned long long c_rays = 0, c_prims = 0, c_inner = 0, c_leaf = 0, c_tri = 0, c_alpha = 0, c_texel = 0, c_over = 0, c_paths = 0;
+    unsigned long long c_rays = 0, c_prims = 0, c_inner = 0, c_leaf = 0, c_tri = 0, c_alpha = 0, c_texel = 0, c_over = 0, c_paths = 0, c_shadow = 0;
     unsigned long long r_prim = 0, r_inner = 0, r_leaf = 0, r_batch = 0; // wave-uniform
     ShadeCounts cnt;
 
@@ -140,6 +146,8 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     f3 lo = F3(0, 0, 0), ld = F3(0, 0, 1), lidir = ld;
     float scale = 1.0f, best_t = 0.0f;
     int32_t best_i = -1;
+    auto in_shadow = [&]() -> bool { return SUN && (bounce & RT_PATH_SHADOW_BIT) != 0u; };
+    auto counted = [&]() -> bool { return COUNT && !in_shadow(); }; // the staged pipeline walks shadow rays without counting
 
     // the ray is traced
     auto retire = [&]() {
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         cur_first = first;
         cur_count = count;
         st = count > 0u ? ST_LEAF : ST_INNER;
-        if (COUNT && count > 0u) c_leaf++;
+        if (counted() && count > 0u) c_leaf++;
     };
     auto enter_desc = [&](uint32_t e) {
         uint32_t first = e & 0x07FFFFFFu, count = e >> 27;
@@ -183,17 +191,18 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         else { --sp; enter_desc(stack[sp * RT_WAVE]); }
     };
     // a new segment of the lane's path: what the extend stage does when it fetches a ray
-    auto begin_ray = [&](f3 o, f3 d) {
+    // (`carried`: a shadow ray starts with the overflow flag of the path's last trace(): either paints the pixel)
+    auto begin_ray = [&](f3 o, f3 d, bool carried) {
         ray[0] = o.x; ray[256] = o.y; ray[512] = o.z;
         ray[768] = d.x; ray[1024] = d.y; ray[1280] = d.z;
-        closest_t = 99999999.0f; // shader.wgsl:600
+        closest_t = in_shadow() ? __builtin_inff() : 99999999.0f; // shader.wgsl:600; a shadow ray has no distance bound
         hit_i = -1;
         hit_prim = 0u;
-        pm = 0;
-        if (COUNT) c_rays++;
+        pm = carried ? RT_PM_OVERFLOW : 0u;
+        if (counted()) c_rays++;
         if (d.x != d.x && d.y != d.y && d.z != d.z) { // a direction of NaNs: see k_extend
             if (a.nan_overflow != 0u) pm = RT_PM_OVERFLOW;
-            if (COUNT) {
+            if (counted()) {
                 c_prims += sc.n_prims;
                 c_inner += a.nan_inner;
                 c_leaf += a.nan_leaf;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     // ---- the three traversal steps (as in k_extend), on records the caller has fetched
     // an inner node: its two children (shader.wgsl:496-521)
     auto inner_step = [&](float4 b0, float4 b1, float4 b2, uint2 dsc) {
-        if (COUNT) c_inner++;
+        if (counted()) c_inner++;
         const float left = hit_aabb6(lo, lidir, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
         const float right = hit_aabb6(lo, lidir, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w);
         const bool lmiss = (left < -0.5f || left > best_t);
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
             const bool go_left = rmiss ? true : (lmiss ? false : left < right);
             if (!lmiss && !rmiss) {
                 if (sp < depth) { stack[sp * RT_WAVE] = go_left ? dsc.y : dsc.x; sp++; }
-                else { pm |= RT_PM_OVERFLOW; if (COUNT) c_over++; } // shader.wgsl:306-313
+                else { pm |= RT_PM_OVERFLOW; if (counted()) c_over++; } // shader.wgsl:306-313
             }
             enter_desc(go_left ? dsc.x : dsc.y);
         }
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     // up to two triangles of the lane's leaf (shader.wgsl:458-495)
     auto leaf_step = [&](rt_float3 a0, rt_float3 a1, rt_float3 a2, rt_float3 b0, rt_float3 b1, rt_float3 b2, bool two) {
         auto test = [&](rt_float3 q0, rt_float3 q1, rt_float3 q2, uint32_t tri_i) {
-            if (COUNT) c_tri++;
+            if (counted()) c_tri++;
             float u, v;
             const float t = hit_tri(lo, ld, F3(q0.x, q0.y, q0.z), F3(q1.x, q1.y, q1.z), F3(q2.x, q2.y, q2.z), u, v);
             if (t >= 0.0f && t < best_t) {
@@ -266,7 +275,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         const uint32_t done = two ? 2u : 1u;
         cur_first += done;
         cur_count -= done;
-        if (cur_count == 0u) pop_or_finish();
+        if (in_shadow() && best_i >= 0) { // something lies along the shadow ray: no further node, no further primitive
+            hit_i = best_i;
+            retire();
+        } else if (cur_count == 0u) pop_or_finish();
     };
     // the next candidate primitive, in index order
     auto next_candidate = [&]() -> uint32_t {
@@ -289,9 +301,9 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         ld = td / scale;
         lo = xform_pos(o, inv);
         lidir = rcp3(ld);
-        pm = (pm & RT_PM_OVERFLOW) | p | (((settings >> RT_PRIMX_MODE_SHIFT) & 3u) << RT_PM_MODE_SHIFT);
+        pm = (pm & RT_PM_OVERFLOW) | p | (in_shadow() ? 0u : ((settings >> RT_PRIMX_MODE_SHIFT) & 3u) << RT_PM_MODE_SHIFT); // no alpha test for shadow rays
         const bool nested = (settings & RT_PRIMX_NESTED_ROOT) != 0u;
-        if (COUNT) c_prims++;
+        if (counted()) c_prims++;
         const float troot = hit_aabb_s(lo, lidir, r0, r1);
         const uint32_t root_first = __float_as_uint(r1.z), root_count = __float_as_uint(r1.w);
         best_t = closest_t * scale;
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         if (troot < -0.5f) { // shader.wgsl:448
             advance();
         } else if (nested && troot > best_t) { // see k_extend
-            if (COUNT) c_inner++;
+            if (counted()) c_inner++;
             advance();
         } else {
             enter(root_first, root_count);
@@ -331,19 +343,36 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
 #endif
             bool fresh = false;
             f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+            bool carried = false;
             if (st == ST_SHADE) {
                 f3 origin = F3(ray[0], ray[256], ray[512]), dir = F3(ray[768], ray[1024], ray[1280]);
                 f3 thr = F3(pth[0], pth[256], pth[512]), lit = F3(pth[768], pth[1024], pth[1280]);
                 const bool overflow = (hit_prim >> 31) != 0u;
-                f3 sun_term;
-                int what = shade_segment<COUNT, false, false>(sc, lin_lut, a.term_prob, origin, dir, thr, lit, seed, hit_i, hit_prim & 0x7FFFFFFFu,
-                                                       closest_t, sun_term, cnt);
-                if (what == RT_PATH_BOUNCE && bounce + 1u == a.max_bounces) what = RT_PATH_END; // loop bound, shader.wgsl:898
+                f3 sun_term = F3(0.0f, 0.0f, 0.0f);
+                int what = RT_PATH_END;
+                if (in_shadow()) {
+                    // the shadow ray is traced: lighting, plus the sun term (kept where the throughput
+                    // was) when nothing lies along the ray (shader.wgsl:930-936; k_shadow_resolve)
+                    if (COUNT) c_shadow++;
+                    if (hit_i < 0) lit = lit + thr;
+                } else {
+                    what = shade_segment<COUNT, SUN, false>(sc, lin_lut, a.term_prob, origin, dir, thr, lit, seed, hit_i, hit_prim & 0x7FFFFFFFu,
+                                                            closest_t, sun_term, cnt);
+                    if (what == RT_PATH_BOUNCE && bounce + 1u == a.max_bounces) what = RT_PATH_END; // loop bound, shader.wgsl:898
+                }
                 if (what == RT_PATH_BOUNCE) {
                     bounce++;
                     pth[0] = thr.x; pth[256] = thr.y; pth[512] = thr.z;
                     pth[768] = lit.x; pth[1024] = lit.y; pth[1280] = lit.z;
                     fresh = true;
+                    o = origin;
+                    d = dir;
+                } else if (SUN && what == RT_PATH_SHADOW) {
+                    bounce |= RT_PATH_SHADOW_BIT;
+                    pth[0] = sun_term.x; pth[256] = sun_term.y; pth[512] = sun_term.z;
+                    pth[768] = lit.x; pth[1024] = lit.y; pth[1280] = lit.z;
+                    fresh = true;
+                    carried = overflow;
                     o = origin;
                     d = dir;
                 } else { // shader.wgsl:941-951
@@ -416,7 +445,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                     run_next += min(avail, (uint32_t)__popcll(done_m));
                 }
             }
-            if (fresh) begin_ray(o, d);
+            if (fresh) begin_ray(o, d, carried);
 #ifdef RT_PROBE
             pr_ticks_camera += wall_clock64() - pr_t1;
 #endif
@@ -524,10 +553,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     }
 #endif
     if (COUNT) {
-        const unsigned long long v[13] = {c_rays, c_prims, c_inner, c_leaf, c_tri, c_alpha, c_texel + cnt.texel, c_over, c_paths, cnt.shade, cnt.miss, cnt.kill, 0};
-        const int idx[12] = {C_RAYS, C_PRIMS, C_INNER, C_LEAF, C_TRI, C_ALPHA, C_TEXEL, C_OVERFLOW, C_PATHS, C_SHADE, C_MISS, C_KILL};
+        const unsigned long long v[13] = {c_rays, c_prims, c_inner, c_leaf, c_tri, c_alpha, c_texel + cnt.texel, c_over, c_paths, cnt.shade, cnt.miss, cnt.kill, c_shadow};
+        const int idx[13] = {C_RAYS, C_PRIMS, C_INNER, C_LEAF, C_TRI, C_ALPHA, C_TEXEL, C_OVERFLOW, C_PATHS, C_SHADE, C_MISS, C_KILL, C_SHADOW};
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
+        for (int k = 0; k < 13; k++) {
             const unsigned long long sum = wave_sum(v[k]);
             if (lane == 0 && sum) atomicAdd(&a.counters[idx[k]], sum);
         }

@@ -1150,7 +1150,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk and
         // stacks that fit the LDS column only.
         // (the bound was measured on 256 CUs; a partition of the chip gets its share of it)
-        const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS && !P.enable_sun &&
+        const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS &&
                            c->watchdog_dev != nullptr;
         if (fused) {
             PathArgs pa{};
@@ -1180,7 +1180,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             pa.nan_tri = nanw.tri;
             pa.nan_dropped = nanw.dropped;
             pa.nan_overflow = nanw.dropped ? 1u : 0u;
-            int pblocks = count ? occupancy_blocks(k_path<true>, 256) : occupancy_blocks(k_path<false>, 256);
+            const bool sun = P.enable_sun != 0;
+            int pblocks = sun ? (count ? occupancy_blocks(k_path<true, true>, 256) : occupancy_blocks(k_path<false, true>, 256))
+                              : (count ? occupancy_blocks(k_path<true, false>, 256) : occupancy_blocks(k_path<false, false>, 256));
             if (path_blocks_env > 0) pblocks = std::min(pblocks, path_blocks_env);
             const uint32_t pgrid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * pblocks, (slots + 255) / 256);
             pa.watchdog = c->watchdog_dev;
@@ -1216,8 +1218,13 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
 #endif
             {
                 StageTimer t(c, timing, RTHIP_STAGE_PATH);
-                if (count) hipLaunchKernelGGL(k_path<true>, dim3(pgrid), dim3(256), 0, c->stream, pa);
-                else hipLaunchKernelGGL(k_path<false>, dim3(pgrid), dim3(256), 0, c->stream, pa);
+                if (sun) {
+                    if (count) hipLaunchKernelGGL((k_path<true, true>), dim3(pgrid), dim3(256), 0, c->stream, pa);
+                    else hipLaunchKernelGGL((k_path<false, true>), dim3(pgrid), dim3(256), 0, c->stream, pa);
+                } else {
+                    if (count) hipLaunchKernelGGL((k_path<true, false>), dim3(pgrid), dim3(256), 0, c->stream, pa);
+                    else hipLaunchKernelGGL((k_path<false, false>), dim3(pgrid), dim3(256), 0, c->stream, pa);
+                }
             }
 #ifdef RT_PROBE
             if (pa.probe) {

@@ -57,11 +57,12 @@ def render(ctx, scene, res, calls, flags=0, **kw):
     return ctx.read_accum(), taps, ctx.counters()
 
 
+@pytest.mark.parametrize("sun", [0, 1])
 @pytest.mark.parametrize("name", list(SCENES))
-def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name):
+def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name, sun):
     s, a, res = scenes[name]
     ctx.upload_scene(a)
-    kw = dict(max_bounces=5)
+    kw = dict(max_bounces=5, enable_sun=sun)
     one_by_one = [(1, 1), (2, 1), (3, 1)]
     ref_acc, ref_taps, ref_cnt = render(ctx, s, res, one_by_one, flags=device.FLAG_STAGED, **kw)
     variants = {
@@ -75,9 +76,10 @@ def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name):
         assert np.array_equal(acc, ref_acc), label
         for k in ("tri", "prim", "t", "seed"):
             assert np.array_equal(taps[k], ref_taps[k]), (label, k)
-        for k in EXACT:
+        for k in EXACT + ("shadow_rays",):
             assert cnt[k] == ref_cnt[k], (label, k, cnt[k], ref_cnt[k])
     assert np.all(ref_acc[..., 3] == 3.0)
+    assert (ref_cnt["shadow_rays"] > 0) == (sun == 1)
 
 
 def test_short_path_is_the_one_that_runs(ctx, scenes):
@@ -105,11 +107,11 @@ def test_short_path_is_the_one_that_runs(ctx, scenes):
         assert t["path"]["launches"] == want_path, (n, t)
         assert (t["extend"]["launches"] == 0) == (want_path == 1), (n, t)
     ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
-    # a stack deeper than the short path's LDS column, and the sun option, keep the staged pipeline
-    for kw in (dict(stack_depth=40), dict(enable_sun=1)):
+    # a stack deeper than the short path's LDS column keeps the staged pipeline; the sun option does not
+    for kw, want_path in ((dict(stack_depth=40), 0), (dict(enable_sun=1), 1)):
         ctx.reset_timing()
         ctx.render(1, 1, 1, device.default_params(flags=device.FLAG_TIMING, **kw))
-        assert ctx.timing()["path"]["launches"] == 0, kw
+        assert ctx.timing()["path"]["launches"] == want_path, kw
 
 
 @pytest.mark.parametrize("name", ["materials", "atrium"])
@@ -145,12 +147,14 @@ def test_short_path_converges_to_the_oracle_image(ctx, scenes):
     assert psnr(tonemapped(acc), tonemapped(ref["accum"])) >= 45.0
 
 
+@pytest.mark.parametrize("sun", [0, 1])
 @pytest.mark.parametrize("depth", [2, 5, 23])
-def test_short_path_drops_pushes_like_the_staged_pipeline(ctx, scenes, depth):
+def test_short_path_drops_pushes_like_the_staged_pipeline(ctx, scenes, depth, sun):
+    """With the sun option a shadow ray's own dropped push paints the pixel too (shader.wgsl:306-313, 941-943)."""
     s, a, res = scenes["terrain"]
     ctx.upload_scene(a)
-    acc0, taps0, cnt0 = render(ctx, s, res, [(1, 2)], flags=device.FLAG_STAGED, stack_depth=depth)
-    acc1, taps1, cnt1 = render(ctx, s, res, [(1, 2)], stack_depth=depth)
+    acc0, taps0, cnt0 = render(ctx, s, res, [(1, 2)], flags=device.FLAG_STAGED, stack_depth=depth, enable_sun=sun)
+    acc1, taps1, cnt1 = render(ctx, s, res, [(1, 2)], stack_depth=depth, enable_sun=sun)
     assert np.array_equal(acc0, acc1)
     assert np.array_equal(taps0["seed"], taps1["seed"]) and np.array_equal(taps0["tri"], taps1["tri"])
     for k in EXACT:
