@@ -110,7 +110,7 @@ def test_config2_suzanne_glb_512_64_samples(ctx):
 
 
 def test_config2_as_worded_suzanne_with_sun_and_trail_hdr(ctx):
-    """Configuration 2 as BASELINE.json words it: "sun + trail.hdr HDRI".  The live shader has no sun
+    """Configuration 2 as the benchmark definition words it: "sun + trail.hdr HDRI".  The live shader has no sun
     (the block is commented out, shader.wgsl:916-937), so this is the opt-in enable_sun = 1 against
     the oracle's restatement of that block, from a camera that fills the frame with the head."""
     s, a = load_reference_scene("suzanne")
