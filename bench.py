@@ -294,6 +294,13 @@ def main():
         # the ranks are children of this process; nothing here has touched a GPU
         return subprocess.run(launch[1]).returncode
 
+    # Libraries underneath write to file descriptor 1 on their own (RCCL prints a version banner when
+    # its communicator is made): the run's standard output is kept for the one JSON line, everything
+    # else that would go there goes to standard error.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     from raytracer_amd import device
 
@@ -619,7 +626,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(arrays, uniforms, p_plain)
         if mode == "single" and not args.no_hbm_case:
             out["roofline"]["hbm_case"] = hbm_case(ctx, args, device)   # last: it replaces the scene in ctx
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if grp is not None:
         grp.close()
