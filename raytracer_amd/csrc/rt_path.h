@@ -15,9 +15,8 @@
 // result depends on (one writer per accumulation slot, frames summed in frame order afterwards).
 //
 // Frame groups of at most RT_PATH_MAX_SLOTS camera paths (two 1080p frames; any group of a small
-// image), scenes of up to 128 primitives (one chunk of candidates) and traversal stacks that fit
-// the LDS column; everything else keeps the staged pipeline, which is the faster one once its
-// launches are long.
+// image) and scenes of up to 128 primitives (one chunk of candidates); everything else keeps the
+// staged pipeline, which is the faster one once its launches are long.
 #pragma once
 
 #include "rt_kernels.h"
@@ -80,6 +79,7 @@ struct PathArgs {
     int32_t*  tap_prim;
     float*    tap_t;
     uint32_t* tap_seed;
+    uint32_t* spill;          // DEEP only: stack levels beyond the LDS column, one dword column per thread of the grid
     uint32_t* watchdog;       // set to 1 by a wave that ran into RT_PATH_WATCHDOG
     // Longest first: camera paths are handed out in runs of 64 slots; run r of the call renders the
     // slots of run order[r] (a permutation of the runs, expensive ones first; null = as they come),
@@ -100,7 +100,9 @@ struct PathArgs {
 // (trace_bvh_shadow, shader.wgsl:528-575), not counted by the traversal counters -- what the
 // ANYHIT instantiation of k_extend does -- and the path round after it is the path's end.
 #define RT_PATH_SHADOW_BIT 0x80000000u
-template <bool COUNT, bool SUN>
+// DEEP: stack_depth above the LDS column (trees of tens of millions of triangles): the levels beyond
+// it live in a global-memory column per thread, as in k_extend.
+template <bool COUNT, bool SUN, bool DEEP>
 __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     __shared__ uint32_t lds_stack[4 * RT_PATH_LDS_LEVELS * RT_WAVE];
     __shared__ float lds_ray[6 * 256];   // world-space origin and direction of the lane's current ray
@@ -115,7 +117,11 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     const uint32_t lane = lane_id();
     uint32_t* const stack = lds_stack + (threadIdx.x >> 6) * (RT_PATH_LDS_LEVELS * RT_WAVE) + lane;
     const uint32_t n = a.n_slots;
-    const uint32_t depth = min(a.stack_depth, RT_PATH_LDS_LEVELS);
+    const uint32_t depth = DEEP ? min(a.stack_depth, RT_MAX_STACK) : min(a.stack_depth, RT_PATH_LDS_LEVELS);
+    const size_t spill_stride = (size_t)gridDim.x * blockDim.x;
+    auto spill_at = [&](uint32_t level) -> uint32_t& {
+        return a.spill[(size_t)(level - RT_PATH_LDS_LEVELS) * spill_stride + (blockIdx.x * blockDim.x + threadIdx.x)];
+    };
     const SceneDev& sc = a.sc;
     const void* const nodes = sc.nodes;
     const void* const tris = sc.tris;
@@ -187,8 +193,15 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         enter(first, count);
     };
     auto pop_or_finish = [&]() {
-        if (sp == 0u) finish();
-        else { --sp; enter_desc(stack[sp * RT_WAVE]); }
+        if (sp == 0u) {
+            finish();
+        } else {
+            --sp;
+            uint32_t e; // two separate loads, see k_extend
+            if (DEEP && sp >= RT_PATH_LDS_LEVELS) e = *const_cast<volatile uint32_t*>(&spill_at(sp));
+            else e = stack[sp * RT_WAVE];
+            enter_desc(e);
+        }
     };
     // a new segment of the lane's path: what the extend stage does when it fetches a ray
     // (`carried`: a shadow ray starts with the overflow flag of the path's last trace(): either paints the pixel)
@@ -232,7 +245,12 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         } else {
             const bool go_left = rmiss ? true : (lmiss ? false : left < right);
             if (!lmiss && !rmiss) {
-                if (sp < depth) { stack[sp * RT_WAVE] = go_left ? dsc.y : dsc.x; sp++; }
+                if (sp < depth) {
+                    const uint32_t e = go_left ? dsc.y : dsc.x; // the far child, postponed
+                    if (DEEP && sp >= RT_PATH_LDS_LEVELS) spill_at(sp) = e;
+                    else stack[sp * RT_WAVE] = e;
+                    sp++;
+                }
                 else { pm |= RT_PM_OVERFLOW; if (counted()) c_over++; } // shader.wgsl:306-313
             }
             enter_desc(go_left ? dsc.x : dsc.y);

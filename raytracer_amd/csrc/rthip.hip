@@ -405,6 +405,21 @@ template <bool DEEP> void shadow_extend_launch_t(ExtMode m, uint32_t grid, hipSt
     else if (m == EXT_SCAN) hipLaunchKernelGGL((k_extend<false, DEEP, true, true>), dim3(grid), dim3(256), 0, st, ea);
     else hipLaunchKernelGGL((k_extend<false, DEEP, false, true>), dim3(grid), dim3(256), 0, st, ea);
 }
+template <bool COUNT, bool SUN> void path_launch_t(bool deep, uint32_t grid, hipStream_t st, const PathArgs& pa) {
+    if (deep) hipLaunchKernelGGL((k_path<COUNT, SUN, true>), dim3(grid), dim3(256), 0, st, pa);
+    else hipLaunchKernelGGL((k_path<COUNT, SUN, false>), dim3(grid), dim3(256), 0, st, pa);
+}
+void path_launch(bool count, bool sun, bool deep, uint32_t grid, hipStream_t st, const PathArgs& pa) {
+    if (count) { if (sun) path_launch_t<true, true>(deep, grid, st, pa); else path_launch_t<true, false>(deep, grid, st, pa); }
+    else { if (sun) path_launch_t<false, true>(deep, grid, st, pa); else path_launch_t<false, false>(deep, grid, st, pa); }
+}
+template <bool COUNT, bool SUN> int path_occupancy_t(bool deep) {
+    return deep ? occupancy_blocks(k_path<COUNT, SUN, true>, 256) : occupancy_blocks(k_path<COUNT, SUN, false>, 256);
+}
+int path_occupancy(bool count, bool sun, bool deep) {
+    if (count) return sun ? path_occupancy_t<true, true>(deep) : path_occupancy_t<true, false>(deep);
+    return sun ? path_occupancy_t<false, true>(deep) : path_occupancy_t<false, false>(deep);
+}
 void cull_list_launch(uint32_t list_len, uint32_t grid, hipStream_t st, const CullListArgs& la) {
     if (list_len == RT_LIST_LEN_LONG) hipLaunchKernelGGL((k_cull_list<RT_LIST_LEN_LONG>), dim3(grid), dim3(256), 0, st, la);
     else hipLaunchKernelGGL((k_cull_list<RT_LIST_LEN>), dim3(grid), dim3(256), 0, st, la);
@@ -1145,13 +1160,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const bool short_call = nf <= 2u && ga.n_tiles >= 64u;
         ga.spread_shift = short_call ? 2u : 0u;
         if (spread_env == 0 || ((spread_env == 2 || spread_env == 4) && ga.n_tiles >= 64u)) ga.spread_shift = (uint32_t)spread_env;
-        // A call of a few frames runs as ONE persistent launch in which a lane owns a whole path
+        // A small frame group runs as ONE persistent launch in which a lane owns a whole path
         // (rt_path.h): the staged pipeline below would spend most of such a call in the tails of its
-        // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk and
-        // stacks that fit the LDS column only.
+        // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk only.
         // (the bound was measured on 256 CUs; a partition of the chip gets its share of it)
-        const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && P.stack_depth <= RT_PATH_LDS_LEVELS &&
-                           c->watchdog_dev != nullptr;
+        const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && c->watchdog_dev != nullptr;
         if (fused) {
             PathArgs pa{};
             pa.sc = c->sc;
@@ -1180,12 +1193,23 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             pa.nan_tri = nanw.tri;
             pa.nan_dropped = nanw.dropped;
             pa.nan_overflow = nanw.dropped ? 1u : 0u;
-            const bool sun = P.enable_sun != 0;
-            int pblocks = sun ? (count ? occupancy_blocks(k_path<true, true>, 256) : occupancy_blocks(k_path<false, true>, 256))
-                              : (count ? occupancy_blocks(k_path<true, false>, 256) : occupancy_blocks(k_path<false, false>, 256));
+            const bool sun = P.enable_sun != 0, pdeep = P.stack_depth > RT_PATH_LDS_LEVELS;
+            int pblocks = path_occupancy(count, sun, pdeep);
             if (path_blocks_env > 0) pblocks = std::min(pblocks, path_blocks_env);
             const uint32_t pgrid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * pblocks, (slots + 255) / 256);
             pa.watchdog = c->watchdog_dev;
+            pa.spill = nullptr;
+            if (pdeep) { // stack levels beyond the LDS column: one dword column per thread of this grid
+                const uint64_t words = (uint64_t)(RT_MAX_STACK - RT_PATH_LDS_LEVELS) * pgrid * 256;
+                if (c->spill_words < words) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    free_dev_t(c->spill);
+                    c->spill_words = 0;
+                    HIP_TRY(c, hipMalloc((void**)&c->spill, sizeof(uint32_t) * words));
+                    c->spill_words = words;
+                }
+                pa.spill = c->spill;
+            }
             // Longest first: the runs of camera paths in the order of what they cost in the last
             // call of this shape (resolution, frames per call).  A new shape, a new scene or a
             // discarded history (reject_hist: the view has changed) starts from the plain order.
@@ -1218,13 +1242,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
 #endif
             {
                 StageTimer t(c, timing, RTHIP_STAGE_PATH);
-                if (sun) {
-                    if (count) hipLaunchKernelGGL((k_path<true, true>), dim3(pgrid), dim3(256), 0, c->stream, pa);
-                    else hipLaunchKernelGGL((k_path<false, true>), dim3(pgrid), dim3(256), 0, c->stream, pa);
-                } else {
-                    if (count) hipLaunchKernelGGL((k_path<true, false>), dim3(pgrid), dim3(256), 0, c->stream, pa);
-                    else hipLaunchKernelGGL((k_path<false, false>), dim3(pgrid), dim3(256), 0, c->stream, pa);
-                }
+                path_launch(count, sun, pdeep, pgrid, c->stream, pa);
             }
 #ifdef RT_PROBE
             if (pa.probe) {

@@ -190,6 +190,15 @@ def test_config5_tiled_terrain_deep_stack(ctx):
     same = got["seed"] == ref["seed"]
     np.testing.assert_allclose(got["accum"][same], ref["accum"][same], rtol=2e-3, atol=2e-4)
     assert got["counters"]["stack_overflows"] == ref["counters"]["stack_overflows"] == 0
+    # the call above ran as one persistent launch (a small frame group); the staged pipeline gives the same bits
+    p.flags |= device.FLAG_STAGED
+    ctx.set_frame_uniforms(u)
+    ctx.reset_counters()
+    ctx.render(1, 2, 1, p)
+    assert np.array_equal(ctx.read_accum(), got["accum"])
+    staged = ctx.counters()
+    for k in ("rays", "inner_steps", "leaf_steps", "tri_tests", "shade_calls", "misses", "kills"):
+        assert staged[k] == got["counters"][k], k
 
 
 def test_shallow_stack_on_deep_tree_overflows_like_the_oracle(ctx):
@@ -431,6 +440,16 @@ def test_config5_reference_terrain_tiled_to_fifty_million_triangles(ctx):
             del os.environ["RTHIP_FRAMES_IN_FLIGHT"]
         else:
             os.environ["RTHIP_FRAMES_IN_FLIGHT"] = old
+    # one frame per call on the same tree: one persistent launch with the stack's upper levels in
+    # memory, against the staged pipeline, bit for bit
+    single = []
+    for flags in (0, device.FLAG_STAGED):
+        q = device.default_params(max_bounces=4, stack_depth=48, flags=flags)
+        ctx.set_frame_uniforms(u)
+        ctx.render(1, 1, 1, q)
+        ctx.render(2, 1, 1, q)
+        single.append(ctx.read_accum())
+    assert np.array_equal(single[0], single[1]) and np.all(single[0][..., 3] == 2.0)
     # oracle: every 180th row of frame 1, and 300 single rays over the whole extent
     sc = oracle_scene(a)
     op = oracle_params(p)

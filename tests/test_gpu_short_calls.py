@@ -107,8 +107,8 @@ def test_short_path_is_the_one_that_runs(ctx, scenes):
         assert t["path"]["launches"] == want_path, (n, t)
         assert (t["extend"]["launches"] == 0) == (want_path == 1), (n, t)
     ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
-    # a stack deeper than the short path's LDS column keeps the staged pipeline; the sun option does not
-    for kw, want_path in ((dict(stack_depth=40), 0), (dict(enable_sun=1), 1)):
+    # neither a stack deeper than the short path's LDS column nor the sun option asks for the staged pipeline
+    for kw, want_path in ((dict(stack_depth=40), 1), (dict(enable_sun=1), 1), (dict(stack_depth=64, enable_sun=1), 1)):
         ctx.reset_timing()
         ctx.render(1, 1, 1, device.default_params(flags=device.FLAG_TIMING, **kw))
         assert ctx.timing()["path"]["launches"] == want_path, kw
@@ -148,9 +148,10 @@ def test_short_path_converges_to_the_oracle_image(ctx, scenes):
 
 
 @pytest.mark.parametrize("sun", [0, 1])
-@pytest.mark.parametrize("depth", [2, 5, 23])
+@pytest.mark.parametrize("depth", [2, 5, 23, 24, 40])
 def test_short_path_drops_pushes_like_the_staged_pipeline(ctx, scenes, depth, sun):
-    """With the sun option a shadow ray's own dropped push paints the pixel too (shader.wgsl:306-313, 941-943)."""
+    """With the sun option a shadow ray's own dropped push paints the pixel too (shader.wgsl:306-313, 941-943).
+    Depths above 23 continue the stack in memory (columns per thread), in both pipelines."""
     s, a, res = scenes["terrain"]
     ctx.upload_scene(a)
     acc0, taps0, cnt0 = render(ctx, s, res, [(1, 2)], flags=device.FLAG_STAGED, stack_depth=depth, enable_sun=sun)
