@@ -84,15 +84,15 @@ struct GenArgs {
 // the index of its private accumulation slot.
 #define RT_NO_PIXEL 0xFFFFFFFFu
 
-// The camera path of queue slot gid: which pixel of which frame it renders, its random state after
-// the four camera draws, and its ray (shader.wgsl:895-897, 741-779).  False for a lane of an edge
+// Which pixel (px, py) of which frame slot fs queue slot gid renders; false for a lane of an edge
 // tile that falls outside the image.
-__device__ __forceinline__ bool camera_path(const GenArgs& a, uint32_t gid, f3& origin, f3& dir, uint32_t& seed, uint32_t& pix) {
+__device__ __forceinline__ bool slot_pixel(const GenArgs& a, uint32_t gid, uint32_t& px, uint32_t& py, uint32_t& fs) {
     // queue order: tile-major, the frames of a tile next to each other, so that neighbouring
     // runs of 64 slots hold rays through the same pixels (and stay neighbours through the
     // order-preserving compaction of the later bounces)
     const uint32_t run = gid >> 6, l = gid & 63u;
-    const uint32_t tile = run / a.n_frames, fs = run - tile * a.n_frames;
+    const uint32_t tile = run / a.n_frames;
+    fs = run - tile * a.n_frames;
     // Which pixel of which tile lane l of the run renders.  A whole tile per run keeps a wave's
     // rays together (they walk the same nodes), and with it their cost: the rays of a tile full of
     // foliage all take several times the average, and the wave that holds them ends long after the
@@ -109,9 +109,17 @@ __device__ __forceinline__ bool camera_path(const GenArgs& a, uint32_t gid, f3& 
         ly = (q / per_row) * side + (j / side);
         t2 = (tile + q * (a.n_tiles >> sh)) % a.n_tiles; // for every q a bijection of the tiles
     }
-    const uint32_t px = (t2 % a.tiles_x) * 8u + lx;
-    const uint32_t py = (t2 / a.tiles_x) * 8u + ly;
-    if (!(px < a.res_x && py < a.res_y)) return false;
+    px = (t2 % a.tiles_x) * 8u + lx;
+    py = (t2 / a.tiles_x) * 8u + ly;
+    return px < a.res_x && py < a.res_y;
+}
+
+// The camera path of queue slot gid: which pixel of which frame it renders, its random state after
+// the four camera draws, and its ray (shader.wgsl:895-897, 741-779).  False for a lane of an edge
+// tile that falls outside the image.
+__device__ __forceinline__ bool camera_path(const GenArgs& a, uint32_t gid, f3& origin, f3& dir, uint32_t& seed, uint32_t& pix) {
+    uint32_t px, py, fs;
+    if (!slot_pixel(a, gid, px, py, fs)) return false;
     seed = hash21(hash21(px, py), a.first_frame + fs * a.frame_stride); // shader.wgsl:895
     // camera_ray, shader.wgsl:741-779 (basis vectors and fov factor are per-frame constants)
     const f3 origin0 = F3(a.origin[0], a.origin[1], a.origin[2]);

@@ -42,7 +42,10 @@
 // round for them while others still have traversal work: this many, or one in RT_PATH_HEAVY_DIV of
 // the lanes that are in play, whichever is fewer
 #ifndef RT_PATH_HEAVY_LANES
-#define RT_PATH_HEAVY_LANES 24
+#define RT_PATH_HEAVY_LANES 32
+#endif
+#ifndef RT_PATH_HEAVY_NUM
+#define RT_PATH_HEAVY_NUM 1u
 #endif
 #ifndef RT_PATH_HEAVY_DIV
 #define RT_PATH_HEAVY_DIV 2u
@@ -81,11 +84,12 @@ struct PathArgs {
     uint32_t* tap_seed;
     uint32_t* spill;          // DEEP only: stack levels beyond the LDS column, one dword column per thread of the grid
     uint32_t* watchdog;       // set to 1 by a wave that ran into RT_PATH_WATCHDOG
-    // Longest first: camera paths are handed out in runs of 64 slots; run r of the call renders the
-    // slots of run order[r] (a permutation of the runs, expensive ones first; null = as they come),
-    // and what a run's paths cost (wave rounds from their first to their last, summed) is added to
-    // cost[its run], from which the order of the next call on the same view is made.
-    const uint32_t* order;
+    // The order in which the camera paths are handed out (see "hand-out order" below): position ->
+    // queue slot, slots outside the image left out (n_slots then counts the slots that are in it);
+    // null = position s renders slot s.  What a run's paths cost (wave rounds from their first to
+    // their last, summed) is added to cost[run], from which the order of the next call on the same
+    // view is made.
+    const uint32_t* perm;
     uint32_t* cost;
     unsigned long long* counters;
     unsigned long long nan_inner, nan_leaf, nan_tri, nan_dropped; // see ExtArgs
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         // gets its candidate mask.  Run when enough lanes wait for it, measured against the lanes
         // that have traversal work: many while the wave is full, few once its paths run out.
         const uint32_t n_wait = n_shade + (drained ? 0u : n_done);
-        if (n_wait != 0u && (n_trav == 0u || n_wait >= min((uint32_t)RT_PATH_HEAVY_LANES, max(1u, (n_trav + n_wait) / RT_PATH_HEAVY_DIV)))) {
+        if (n_wait != 0u && (n_trav == 0u || n_wait >= min((uint32_t)RT_PATH_HEAVY_LANES, max(1u, (n_trav + n_wait) * RT_PATH_HEAVY_NUM / RT_PATH_HEAVY_DIV)))) {
 #ifdef RT_PROBE
             const unsigned long long pr_t0 = wall_clock64();
             pr_shade++; pr_shade_lanes += n_shade;
@@ -406,7 +410,11 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                         a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
                     }
                     if (a.tap && pix < a.n_pixels) a.tap_seed[pix] = seed;
+#ifdef RT_PATH_COST_MAX
+                    if (a.cost) atomicMax(a.cost + meta[0], iter - meta[256]);
+#else
                     if (a.cost) atomicAdd(a.cost + meta[0], iter - meta[256]);
+#endif
                     st = ST_DONE;
                 }
             }
@@ -449,8 +457,9 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(done_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_m, 0u));
                     if (st == ST_DONE && rank < avail) {
                         const uint32_t s_in = run_next + rank;
-                        const uint32_t run = a.order ? a.order[s_in >> 6] : s_in >> 6;
-                        if (camera_path(a.gen, (run << 6) | (s_in & 63u), o, d, seed, pix)) {
+                        const uint32_t slot = a.perm ? a.perm[s_in] : s_in;
+                        const uint32_t run = slot >> 6;
+                        if (camera_path(a.gen, slot, o, d, seed, pix)) {
                             meta[0] = run;
                             meta[256] = iter;
                             if (COUNT) c_paths++;
@@ -587,17 +596,34 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ longest first
+// ------------------------------------------------------------------ hand-out order
+//
+// A persistent launch ends when its last paths do.  Two things decide how long a path keeps its lane:
+// what a ray costs where the path runs (a tile full of foliage: several times the average), and how
+// many segments the path has -- one of a single segment that starts with the last hand-out is over a
+// few rounds later, one of four needs three more traces and three more path rounds (1080p headline
+// scene, the median wave's end after the last hand-out: 0.03 / 0.23 / 0.46 ms with max_bounces 1 / 2 /
+// 4).  The first is known from the call before: every path adds the wave rounds it was alive for to
+// its run's word of `cost`, and k_order_items sorts the runs by it after a launch (counting sort over
+// 256 levels, stable; whatever the costs are, every run gets exactly one place, because both passes
+// compute the level the same way).  Of the second, one thing is known before the path is traced:
+// whether it outlives its FIRST termination draw (shader.wgsl:907), which is the fifth draw of the
+// pixel's random stream (after the four of camera_ray) unless BLEND alpha draws come before it.  So
+// every run of 64 slots is two ITEMS -- its paths that go on after their first hit ("long") and those
+// that end there or in the sky -- and in a call with many paths per lane the long items of all runs
+// are handed out before the others (`split`), each kind in the order of the runs.  A call with few
+// paths per lane keeps the two items of a run together: its waves start with a whole tile each, whose
+// rays walk the same nodes, and that is worth more there than the order (512 x 512, one path per
+// lane: 1.61 ms against 1.78 split; 1080p, eight per lane: 2.77 against 2.61).  Three small kernels
+// before the launch turn places into the list of slots (`perm`): counts per item, a prefix over the
+// places, the scatter.  All of this decides which lane traces which path when, nothing a path
+// computes (one writer per accumulation slot); where BLEND draws shift the stream the split is merely
+// a worse guess.  (Keys of cost x 2.75 for the long item and cost x 1 for the other, sorted together,
+// were measured too: 2.75 ms at 1080p, i.e. the loss of coherence without the gain.)
 
-// The order in which the next call on this view hands out its runs of camera paths: by what the runs
-// cost in the call before, expensive first.  A persistent launch ends when its last paths do, and
-// paths that start late through foliage keep a few waves busy long after the others have gone; the
-// same paths started first are over while there is still work for everybody.  Whatever the costs
-// are, `order` comes out a permutation of 0 .. n_runs - 1 (a counting sort over 256 cost levels:
-// every run gets exactly one place, whatever level the float arithmetic assigns it, because both
-// passes compute the level the same way), and the result of a render does not depend on it.  One
-// block; also clears the costs for the next call.
-__global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
+// rank[run] = the place of the run when the runs are sorted by cost, expensive first.  One block; also
+// clears the costs for the next call.
+__global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* rank, uint32_t n_runs) {
     // a histogram per wave: most runs fall into a few dozen cost levels, and 1024 threads counting
     // into one set of 256 LDS words spend their time queueing for the same words
     __shared__ uint32_t bucket[16][256];
@@ -665,15 +691,125 @@ __global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* o
             const uint32_t i = base + k * 1024u;
             if (i < n_runs) {
                 const uint32_t l = level(v[k]);
-                order[red[l] + atomicAdd(&bucket[w][l], 1u)] = i;
+                rank[i] = red[l] + atomicAdd(&bucket[w][l], 1u);
                 cost[i] = 0u;
             }
         }
     }
 }
 
-// the order of a first call: as the runs come
-__global__ __launch_bounds__(256) void k_order_identity(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
+// the order of a first call (no costs yet): the runs as they come
+__global__ __launch_bounds__(256) void k_order_first(uint32_t* cost, uint32_t* rank, uint32_t n_runs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_runs) { order[i] = i; cost[i] = 0u; }
+    if (i < n_runs) { rank[i] = i; cost[i] = 0u; }
+}
+
+// items per run: 2 = the paths that outlive their first termination draw / the others; 3 = the first
+// kind again in two, by the draw that is the second termination draw after a diffuse bounce
+#ifndef RT_PLAN_ITEMS
+#define RT_PLAN_ITEMS 2u
+#endif
+
+struct PlanArgs {
+    GenArgs gen;
+    const uint32_t* rank;    // run -> its place among the runs
+    uint32_t  n_runs;
+    uint32_t  split;         // 1: item c of every run before item c + 1 of any; 0: the items of a run next to each other
+    float     term_prob;
+    uint32_t* counts;        // per place of an item: its slots
+    uint32_t* offsets;       // exclusive prefix of counts; [RT_PLAN_ITEMS * n_runs] = the slots inside the image
+    uint32_t* perm;          // hand-out position -> queue slot
+};
+
+// the place of item c (0 = the longest paths) of a run
+__device__ __forceinline__ uint32_t plan_place(const PlanArgs& a, uint32_t run, uint32_t c) {
+    const uint32_t r = a.rank[run];
+    return a.split ? c * a.n_runs + r : RT_PLAN_ITEMS * r + c;
+}
+
+// RT_PLAN_ITEMS: the slot is outside the image; otherwise the item of its run the slot's path belongs to
+__device__ __forceinline__ uint32_t plan_class(const GenArgs& g, uint32_t gid, float term_prob) {
+    uint32_t px, py, fs;
+    if (!slot_pixel(g, gid, px, py, fs)) return RT_PLAN_ITEMS;
+    uint32_t seed = hash21(hash21(px, py), g.first_frame + fs * g.frame_stride); // shader.wgsl:895
+    (void)rnd(seed); (void)rnd(seed); (void)rnd(seed); (void)rnd(seed);        // camera_ray's four draws
+    if (rnd(seed) < term_prob) return RT_PLAN_ITEMS - 1u;                       // shader.wgsl:907
+    if (RT_PLAN_ITEMS == 2u) return 0u;
+    // handle_surface_hit_brdf of a diffuse bounce takes seven draws (shader.wgsl:804, 848, 854, 858, 877); the next is :907 again
+#pragma unroll
+    for (int k = 0; k < 7; k++) (void)rnd(seed);
+    return rnd(seed) < term_prob ? 1u : 0u;
+}
+
+// a wave per run
+__global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
+    const uint32_t run = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (run >= a.n_runs) return;
+    const uint32_t cls = plan_class(a.gen, (run << 6) | lane_id(), a.term_prob);
+#pragma unroll
+    for (uint32_t c = 0; c < RT_PLAN_ITEMS; c++) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(cls == c));
+        if (lane_id() == 0) a.counts[plan_place(a, run, c)] = n;
+    }
+}
+
+// one block: off[i] = counts[0] + ... + counts[i - 1], off[n] = the total.  16 384 counts at a time:
+// each of the sixteen waves takes 1024 consecutive ones as sixteen rows of 64 (every read and write
+// of a wave is one 256-byte piece; a single CU pays per line a wave-level access touches), scans its
+// rows with shuffles -- sixteen independent chains -- and strings them together in registers; the
+// waves' totals meet in LDS: one barrier per 16 384 counts.
+__global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* counts, uint32_t* off, uint32_t n) {
+    __shared__ uint32_t wsum[2][16];
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63u;
+    uint32_t carry = 0u, buf = 0u;
+    for (uint32_t base = 0; base < n; base += 16384u) {
+        const uint32_t first = base + w * 1024u + lane;
+        uint32_t v[16], incl[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) { const uint32_t i = first + k * 64u; v[k] = i < n ? counts[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) incl[k] = v[k];
+        for (uint32_t o = 1u; o < 64u; o <<= 1) {
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl[k], o, 64);
+                if (lane >= o) incl[k] += up;
+            }
+        }
+        uint32_t row_before[16], run = 0u; // the rows of this wave that come before row k
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) {
+            row_before[k] = run;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl[k], 63);
+        }
+        if (lane == 0u) wsum[buf][w] = run;
+        __syncthreads();
+        uint32_t before = 0u, total = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++) { const uint32_t x = wsum[buf][j]; total += x; if (j < w) before += x; }
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) {
+            const uint32_t i = first + k * 64u;
+            if (i < n) off[i] = carry + before + row_before[k] + incl[k] - v[k];
+        }
+        carry += total;
+        buf ^= 1u; // the next batch's sums go to the other row: one barrier per batch is enough
+    }
+    if (t == 0) off[n] = carry;
+}
+
+// a wave per run
+__global__ __launch_bounds__(256) void k_plan_scatter(PlanArgs a) {
+    const uint32_t run = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (run >= a.n_runs) return;
+    const uint32_t gid = (run << 6) | lane_id();
+    const uint32_t cls = plan_class(a.gen, gid, a.term_prob);
+#pragma unroll
+    for (uint32_t c = 0; c < RT_PLAN_ITEMS; c++) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            a.perm[a.offsets[plan_place(a, run, c)] + rank] = gid;
+        }
+    }
 }

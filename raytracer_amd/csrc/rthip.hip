@@ -129,8 +129,10 @@ struct rthip_ctx {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* path_cost = nullptr;   // k_path: what each run of camera paths cost in the last short call, and the
-    uint32_t* path_order = nullptr;  // order (expensive first) in which the next one hands them out
+    uint32_t* path_rank = nullptr;   // place of each run in the order (expensive first) in which the next one hands them out
     uint64_t  path_runs_cap = 0;
+    uint32_t* path_plan = nullptr;   // k_plan_*: per place, the count of its slots and the prefix of the counts
+    uint32_t* path_perm = nullptr;   // hand-out position -> queue slot (64 words per run)
     uint32_t  order_runs = 0, order_res_x = 0, order_res_y = 0, order_frames = 0, order_spread = 0; // what the order was made for (0 runs: none)
     uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
     uint32_t* watchdog_dev = nullptr;  // the same word as the device sees it
@@ -203,7 +205,9 @@ void free_work_buffers(rthip_ctx* c) {
     free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
     free_dev_t(c->cand_lists);
     free_dev_t(c->path_cost);
-    free_dev_t(c->path_order);
+    free_dev_t(c->path_rank);
+    free_dev_t(c->path_plan);
+    free_dev_t(c->path_perm);
     c->path_runs_cap = 0;
     c->order_runs = 0;
     c->cand_cap = 0;
@@ -1089,6 +1093,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     if (const char* e = knob(c, "RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
     bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
     if (const char* e = knob(c, "RTHIP_FORCE_STAGED")) staged_only = staged_only || std::atoi(e) != 0; // tests: a whole module through the staged pipeline
+    int split_env = -1;
+    if (const char* e = knob(c, "RTHIP_PATH_SPLIT")) split_env = std::atoi(e); // experiment knob: 1 / 0 = long paths of all runs first / every run's paths together
     int lpt_env = 1;
     if (const char* e = knob(c, "RTHIP_PATH_LONGEST_FIRST")) lpt_env = std::atoi(e); // experiment knob: 0 = runs as they come
 
@@ -1169,7 +1175,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             PathArgs pa{};
             pa.sc = c->sc;
             pa.gen = ga;
-            pa.gen.spread_shift = (ga.n_tiles >= 64u && spread_env != 0) ? (spread_env == 4 ? 4u : 2u) : 0u;
+            pa.gen.spread_shift = (ga.n_tiles >= 64u && spread_env > 0) ? (spread_env == 4 ? 4u : 2u) : 0u;
             pa.gen.counters = nullptr;
             pa.cursor = c->ctrl + 64;
             pa.n_slots = (uint32_t)slots;
@@ -1210,29 +1216,51 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 }
                 pa.spill = c->spill;
             }
-            // Longest first: the runs of camera paths in the order of what they cost in the last
-            // call of this shape (resolution, frames per call).  A new shape, a new scene or a
-            // discarded history (reject_hist: the view has changed) starts from the plain order.
+            // Hand-out order (rt_path.h): the camera paths of expensive tiles first, and of every tile
+            // first those that outlive their first termination draw, by what the runs cost in the
+            // last call of this shape (resolution, frames per call).  A new shape, a new scene or a
+            // discarded history (reject_hist: the view has changed) starts without costs.
             const uint32_t n_runs = (uint32_t)(slots >> 6);
+            // long paths of all runs first where a lane gets six camera paths or more (measured: 1080p and up on 256 CUs)
+            uint32_t split = slots >= 6ull * 256ull * pgrid ? 1u : 0u;
+            if (split_env >= 0) split = split_env ? 1u : 0u;
             if (lpt_env != 0) {
                 if (c->path_runs_cap < n_runs) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     free_dev_t(c->path_cost);
-                    free_dev_t(c->path_order);
+                    free_dev_t(c->path_rank);
+                    free_dev_t(c->path_plan);
+                    free_dev_t(c->path_perm);
                     c->path_runs_cap = 0;
                     c->order_runs = 0;
                     HIP_TRY(c, hipMalloc((void**)&c->path_cost, sizeof(uint32_t) * n_runs));
-                    HIP_TRY(c, hipMalloc((void**)&c->path_order, sizeof(uint32_t) * n_runs));
+                    HIP_TRY(c, hipMalloc((void**)&c->path_rank, sizeof(uint32_t) * (size_t)n_runs));
+                    HIP_TRY(c, hipMalloc((void**)&c->path_plan, sizeof(uint32_t) * (2 * RT_PLAN_ITEMS * (size_t)n_runs + 1)));
+                    HIP_TRY(c, hipMalloc((void**)&c->path_perm, sizeof(uint32_t) * 64 * (size_t)n_runs));
                     c->path_runs_cap = n_runs;
                 }
                 const bool same = c->order_runs == n_runs && c->order_res_x == c->res_x && c->order_res_y == c->res_y && c->order_frames == nf &&
                                   c->order_spread == pa.gen.spread_shift && !overwrite;
                 if (!same) {
-                    hipLaunchKernelGGL(k_order_identity, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_order, n_runs);
+                    hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_rank, n_runs);
                     c->order_runs = n_runs; c->order_res_x = c->res_x; c->order_res_y = c->res_y; c->order_frames = nf; c->order_spread = pa.gen.spread_shift;
                 }
-                pa.order = c->path_order;
+                PlanArgs pl{};
+                pl.gen = pa.gen;
+                pl.rank = c->path_rank;
+                pl.split = split;
+                pl.n_runs = n_runs;
+                pl.term_prob = P.term_prob;
+                pl.counts = c->path_plan;
+                pl.offsets = c->path_plan + RT_PLAN_ITEMS * (size_t)n_runs;
+                pl.perm = c->path_perm;
+                const uint32_t plan_grid = (n_runs + 3u) / 4u;
+                hipLaunchKernelGGL(k_plan_count, dim3(plan_grid), dim3(256), 0, c->stream, pl);
+                hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)pl.counts, pl.offsets, RT_PLAN_ITEMS * n_runs);
+                hipLaunchKernelGGL(k_plan_scatter, dim3(plan_grid), dim3(256), 0, c->stream, pl);
+                pa.perm = c->path_perm;
                 pa.cost = c->path_cost;
+                pa.n_slots = (uint32_t)(c->n_pixels * nf); // the slots that are inside the image
             }
 #ifdef RT_PROBE
             // diagnostic build only (tools/path_probe.py): per-wave records of this launch appended to $RTHIP_PROBE_FILE
@@ -1263,7 +1291,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
                                    (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
             }
-            if (pa.order) hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, c->stream, c->path_cost, c->path_order, n_runs);
+            if (pa.cost) hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, c->stream, c->path_cost, c->path_rank, n_runs);
             c->reject_hist = 0; // main.rs:403
             if (tap_group) c->taps_valid = true;
             continue;
