@@ -66,7 +66,7 @@ typedef struct {
 #define RTHIP_FLAG_COUNTERS 1u   /* maintain rthip_counters (small cost)                       */
 #define RTHIP_FLAG_TAPS     2u   /* record primary hits + final seeds of the first frame       */
 #define RTHIP_FLAG_TIMING   4u   /* bracket every stage launch with HIP events (rthip_timing)  */
-#define RTHIP_FLAG_STAGED   8u   /* small frame groups (up to 5 * 2^20 camera paths) too go through the staged pipeline
+#define RTHIP_FLAG_STAGED   8u   /* small frame groups (up to 8 * 2^20 camera paths) too go through the staged pipeline
                                     (generate / cull / extend / shade launches per bounce) instead of
                                     the single launch in which a lane owns a whole path; the result
                                     is the same bit for bit                                       */

@@ -14,7 +14,7 @@
 // operand order), so its result is bit-identical; paths only finish in another order, which no
 // result depends on (one writer per accumulation slot, frames summed in frame order afterwards).
 //
-// Frame groups of at most RT_PATH_MAX_SLOTS camera paths (two 1080p frames; any group of a small
+// Frame groups of at most RT_PATH_MAX_SLOTS camera paths (four 1080p frames; any group of a small
 // image) and scenes of up to 128 primitives (one chunk of candidates); everything else keeps the
 // staged pipeline, which is the faster one once its launches are long.
 #pragma once
@@ -29,11 +29,12 @@
 #endif
 #ifndef RT_PATH_MAX_SLOTS
 // A frame group runs this way if it has at most this many camera paths (whatever its number of
-// frames): beyond, the staged pipeline's tails weigh less than this kernel's lower rate.  This
-// kernel's time over the staged pipeline's, 1080p atrium: 512x512 x 1 / 4 / 16 frames 0.61 / 0.69 /
-// 0.89; 720p x 1 / 3 / 5: 0.65 / 0.77 / 0.94; 1080p x 1 / 2 / 3: 0.79 / 0.94 / 1.06; 1440p x 1 / 2:
-// 0.92 / 1.11; 4K x 1: 1.11.
-#define RT_PATH_MAX_SLOTS (5u << 20)
+// frames): beyond, the staged pipeline's tails weigh less than this kernel's lower rate.  Wall time
+// of a call, this kernel / staged pipeline, 1080p headline scene on 256 CUs: 1080p x 1 / 2 / 3 / 4
+// frames 2.73 / 4.66 / 6.65 / 8.62 ms against 3.88 / 5.55 / 7.22 / 8.63; 1440p x 1 / 2: 4.20 / 7.73
+// against 5.25 / 7.93; 4K x 1: 8.58 against 8.69; 720p x 5 / 8: 5.14 / 7.82 against 6.10 / 8.13;
+// 512 x 512 x 16 / 32: 4.69 / 8.71 against 5.82 / 8.94.
+#define RT_PATH_MAX_SLOTS (8u << 20)
 #endif
 #ifndef RT_PATH_LDS_LEVELS
 #define RT_PATH_LDS_LEVELS 23u   // the reference's stack depth (shader.wgsl:303)
@@ -134,6 +135,9 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
     ShadeCounts cnt;
 
     uint32_t run_next = 0, run_end = 0, cursor_seen = 0, iter = 0;
+#ifdef RT_PROBE2
+    uint32_t pr_last_start = 0, pr_last_end = 0, pr_last_b = 0, pr_last_run = 0, pr2_start = 0, pr2_end = 0, pr2_b = 0, pr2_run = 0;
+#endif
     bool drained = false;
 #ifdef RT_PROBE
     const unsigned long long pr_start = wall_clock64();
@@ -410,6 +414,9 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
                         a.partial[pix] = make_float4(lit.x, lit.y, lit.z, 1.0f);
                     }
                     if (a.tap && pix < a.n_pixels) a.tap_seed[pix] = seed;
+#ifdef RT_PROBE2
+                    pr_last_start = meta[256]; pr_last_end = iter; pr_last_b = bounce & 0xFFu; pr_last_run = meta[0];
+#endif
 #ifdef RT_PATH_COST_MAX
                     if (a.cost) atomicMax(a.cost + meta[0], iter - meta[256]);
 #else
@@ -568,6 +575,19 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
             }
         }
     }
+#ifdef RT_PROBE2
+    { // the path of this wave that ended last: when it started, when it ended, its segments
+        uint32_t best = pr_last_end, who = lane;
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t ob = (uint32_t)__shfl_xor((int)best, o, 64), ow = (uint32_t)__shfl_xor((int)who, o, 64);
+            if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
+        }
+        pr2_start = (uint32_t)__shfl((int)pr_last_start, (int)who, 64);
+        pr2_end = best;
+        pr2_b = (uint32_t)__shfl((int)pr_last_b, (int)who, 64);
+        pr2_run = (uint32_t)__shfl((int)pr_last_run, (int)who, 64);
+    }
+#endif
 #ifdef RT_PROBE
     if (a.probe && lane == 0) {
         unsigned long long* r = a.probe + 8ull * ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -577,6 +597,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
         r[5] = pr_lanes_tail | (pr_heavy_ticks << 32);                         // ... after the drain; ticks spent in path rounds
         r[6] = pr_shade | ((unsigned long long)pr_shade_lanes << 32);
         r[7] = pr_scan | ((unsigned long long)(pr_ticks_camera >> 4) << 32);
+#ifdef RT_PROBE2
+        r[6] = pr2_start | ((unsigned long long)pr2_end << 32);
+        r[7] = pr2_b | ((unsigned long long)pr2_run << 8) | ((unsigned long long)iter << 32);
+#endif
     }
 #endif
     if (COUNT) {

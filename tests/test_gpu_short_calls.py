@@ -1,4 +1,4 @@
-"""Frame groups of at most 5 * 2^20 camera paths (two 1080p frames; any group of a small image) run
+"""Frame groups of at most 8 * 2^20 camera paths (four 1080p frames; any group of a small image) run
 as one persistent launch in which a lane owns a whole path (k_path); larger ones, and calls with
 RTHIP_FLAG_STAGED, go through the staged pipeline (generate / cull / extend / shade per bounce).  Both run the same code per path, so everything they produce must
 be equal bit for bit -- accumulators, primary-hit taps, final RNG states, traversal counters -- and
@@ -83,9 +83,9 @@ def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name, sun):
 
 
 def test_short_path_is_the_one_that_runs(ctx, scenes):
-    """Timing records which launches a call made: a frame group of at most 5 * 2^20 camera paths =
+    """Timing records which launches a call made: a frame group of at most 8 * 2^20 camera paths =
     one k_path launch and no stage launch (15 360 per frame here: any group); more = the staged
-    pipeline (a 1080p frame has 2 073 600: two frames run as one launch, three are staged)."""
+    pipeline (a 1080p frame has 2 073 600: four frames run as one launch, five are staged)."""
     s, a, res = scenes["materials"]
     ctx.upload_scene(a)
     ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
@@ -100,7 +100,7 @@ def test_short_path_is_the_one_that_runs(ctx, scenes):
     ctx.render(1, 65, 1, p)          # two frame groups (64 frames in flight): two launches
     assert ctx.timing()["path"]["launches"] == 2
     ctx.set_frame_uniforms(s.frame_uniforms((1920, 1080), frame=1, reject_hist=1))
-    for n, want_path in ((2, 1), (3, 0)):
+    for n, want_path in ((4, 1), (5, 0)):
         ctx.reset_timing()
         ctx.render(1, n, 1, p)
         t = ctx.timing()
