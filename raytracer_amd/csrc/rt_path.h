@@ -55,6 +55,11 @@
 #ifndef RT_PATH_EXACT_LEFT
 #define RT_PATH_EXACT_LEFT 0xFFFFFFFFu
 #endif
+// inner-node steps a lane takes in a round that the inner nodes have won (2 / 3 / 4 / 6: 2.66 / 2.62 /
+// 2.59 / 2.65 ms of kernel per 1080p frame)
+#ifndef RT_PATH_INNER_BURST
+#define RT_PATH_INNER_BURST 4
+#endif
 #ifndef RT_PATH_RUN_SLOTS
 #define RT_PATH_RUN_SLOTS 64u
 #endif
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
 
         if (n_inner >= n_prim && n_inner >= n_leaf) {
 #pragma unroll 1
-            for (int burst = 0; burst < RT_INNER_BURST; burst++) {
+            for (int burst = 0; burst < RT_PATH_INNER_BURST; burst++) {
                 if (COUNT) r_inner++;
                 if (st == ST_INNER) {
                     const float4* np = rec16(sc.pairs, cur_first * 2u);
