@@ -650,9 +650,9 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void k_path(PathArgs a) {
 // a worse guess.  (Keys of cost x 2.75 for the long item and cost x 1 for the other, sorted together,
 // were measured too: 2.75 ms at 1080p, i.e. the loss of coherence without the gain.)
 
-// rank[run] = the place of the run when the runs are sorted by cost, expensive first.  One block; also
-// clears the costs for the next call.
-__global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* rank, uint32_t n_runs) {
+// order[place] = run: the runs sorted by cost, expensive first.  One block; also clears the costs for
+// the next call.
+__global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
     // a histogram per wave: most runs fall into a few dozen cost levels, and 1024 threads counting
     // into one set of 256 LDS words spend their time queueing for the same words
     __shared__ uint32_t bucket[16][256];
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* r
             const uint32_t i = base + k * 1024u;
             if (i < n_runs) {
                 const uint32_t l = level(v[k]);
-                rank[i] = red[l] + atomicAdd(&bucket[w][l], 1u);
+                order[red[l] + atomicAdd(&bucket[w][l], 1u)] = i;
                 cost[i] = 0u;
             }
         }
@@ -728,117 +728,101 @@ __global__ __launch_bounds__(1024) void k_order_runs(uint32_t* cost, uint32_t* r
 }
 
 // the order of a first call (no costs yet): the runs as they come
-__global__ __launch_bounds__(256) void k_order_first(uint32_t* cost, uint32_t* rank, uint32_t n_runs) {
+__global__ __launch_bounds__(256) void k_order_first(uint32_t* cost, uint32_t* order, uint32_t n_runs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_runs) { rank[i] = i; cost[i] = 0u; }
+    if (i < n_runs) { order[i] = i; cost[i] = 0u; }
 }
-
-// items per run: 2 = the paths that outlive their first termination draw / the others; 3 = the first
-// kind again in two, by the draw that is the second termination draw after a diffuse bounce
-#ifndef RT_PLAN_ITEMS
-#define RT_PLAN_ITEMS 2u
-#endif
 
 struct PlanArgs {
     GenArgs gen;
-    const uint32_t* rank;    // run -> its place among the runs
+    const uint32_t* order;   // place -> run
     uint32_t  n_runs;
-    uint32_t  split;         // 1: item c of every run before item c + 1 of any; 0: the items of a run next to each other
+    uint32_t  split;         // 1: the long items of all runs before the others; 0: the two items of a run next to each other
     float     term_prob;
-    uint32_t* counts;        // per place of an item: its slots
-    uint32_t* offsets;       // exclusive prefix of counts; [RT_PLAN_ITEMS * n_runs] = the slots inside the image
+    uint32_t* counts;        // per place: the slots of its long item, of its other item
+    uint32_t* block_sums;    // per block of RT_PLAN_BLOCK_RUNS places: the same, summed
     uint32_t* perm;          // hand-out position -> queue slot
+    uint32_t* cursor;        // k_path's hand-out cursor: cleared here
 };
+#define RT_PLAN_WAVE_RUNS  4u                            // places a wave takes, one after the other
+#define RT_PLAN_BLOCK_RUNS (16u * RT_PLAN_WAVE_RUNS)   // a block of 1024 threads
 
-// the place of item c (0 = the longest paths) of a run
-__device__ __forceinline__ uint32_t plan_place(const PlanArgs& a, uint32_t run, uint32_t c) {
-    const uint32_t r = a.rank[run];
-    return a.split ? c * a.n_runs + r : RT_PLAN_ITEMS * r + c;
-}
-
-// RT_PLAN_ITEMS: the slot is outside the image; otherwise the item of its run the slot's path belongs to
+// 0: the path of this slot outlives its first termination draw; 1: it does not; 2: the slot is outside the image
 __device__ __forceinline__ uint32_t plan_class(const GenArgs& g, uint32_t gid, float term_prob) {
     uint32_t px, py, fs;
-    if (!slot_pixel(g, gid, px, py, fs)) return RT_PLAN_ITEMS;
+    if (!slot_pixel(g, gid, px, py, fs)) return 2u;
     uint32_t seed = hash21(hash21(px, py), g.first_frame + fs * g.frame_stride); // shader.wgsl:895
     (void)rnd(seed); (void)rnd(seed); (void)rnd(seed); (void)rnd(seed);        // camera_ray's four draws
-    if (rnd(seed) < term_prob) return RT_PLAN_ITEMS - 1u;                       // shader.wgsl:907
-    if (RT_PLAN_ITEMS == 2u) return 0u;
-    // handle_surface_hit_brdf of a diffuse bounce takes seven draws (shader.wgsl:804, 848, 854, 858, 877); the next is :907 again
-#pragma unroll
-    for (int k = 0; k < 7; k++) (void)rnd(seed);
-    return rnd(seed) < term_prob ? 1u : 0u;
+    return rnd(seed) < term_prob ? 1u : 0u;                                     // shader.wgsl:907
 }
 
-// a wave per run
-__global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
-    const uint32_t run = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (run >= a.n_runs) return;
-    const uint32_t cls = plan_class(a.gen, (run << 6) | lane_id(), a.term_prob);
+// Two kernels make `perm`.  The first counts, per place, the slots of either kind, and per block of
+// 64 places their sums; the second gives every block the sums of the blocks before it (each block
+// adds them up for itself: a few hundred words out of the L2) and writes the slots out.
+__global__ __launch_bounds__(1024) void k_plan_count(PlanArgs a) {
+    __shared__ uint32_t cnt[2][RT_PLAN_BLOCK_RUNS];
+    const uint32_t w = threadIdx.x >> 6;
 #pragma unroll
-    for (uint32_t c = 0; c < RT_PLAN_ITEMS; c++) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(cls == c));
-        if (lane_id() == 0) a.counts[plan_place(a, run, c)] = n;
+    for (uint32_t i = 0; i < RT_PLAN_WAVE_RUNS; i++) {
+        const uint32_t q = w * RT_PLAN_WAVE_RUNS + i, p = blockIdx.x * RT_PLAN_BLOCK_RUNS + q;
+        uint32_t cls = 2u;
+        if (p < a.n_runs) cls = plan_class(a.gen, (a.order[p] << 6) | lane_id(), a.term_prob);
+        const uint32_t nl = (uint32_t)__popcll(__ballot(cls == 0u)), ns = (uint32_t)__popcll(__ballot(cls == 1u));
+        if (lane_id() == 0) {
+            cnt[0][q] = nl; cnt[1][q] = ns;
+            if (p < a.n_runs) { a.counts[2u * p] = nl; a.counts[2u * p + 1u] = ns; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64u) { // RT_PLAN_BLOCK_RUNS = 64 places: one per lane of the first wave
+        uint32_t sl = cnt[0][threadIdx.x], ss = cnt[1][threadIdx.x];
+        for (int o = 32; o > 0; o >>= 1) { sl += (uint32_t)__shfl_xor((int)sl, o, 64); ss += (uint32_t)__shfl_xor((int)ss, o, 64); }
+        if (threadIdx.x == 0) {
+            a.block_sums[2u * blockIdx.x] = sl; a.block_sums[2u * blockIdx.x + 1u] = ss;
+            if (blockIdx.x == 0) *a.cursor = 0u;
+        }
     }
 }
 
-// one block: off[i] = counts[0] + ... + counts[i - 1], off[n] = the total.  16 384 counts at a time:
-// each of the sixteen waves takes 1024 consecutive ones as sixteen rows of 64 (every read and write
-// of a wave is one 256-byte piece; a single CU pays per line a wave-level access touches), scans its
-// rows with shuffles -- sixteen independent chains -- and strings them together in registers; the
-// waves' totals meet in LDS: one barrier per 16 384 counts.
-__global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* counts, uint32_t* off, uint32_t n) {
-    __shared__ uint32_t wsum[2][16];
-    const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63u;
-    uint32_t carry = 0u, buf = 0u;
-    for (uint32_t base = 0; base < n; base += 16384u) {
-        const uint32_t first = base + w * 1024u + lane;
-        uint32_t v[16], incl[16];
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) { const uint32_t i = first + k * 64u; v[k] = i < n ? counts[i] : 0u; }
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) incl[k] = v[k];
-        for (uint32_t o = 1u; o < 64u; o <<= 1) {
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; k++) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl[k], o, 64);
-                if (lane >= o) incl[k] += up;
-            }
-        }
-        uint32_t row_before[16], run = 0u; // the rows of this wave that come before row k
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) {
-            row_before[k] = run;
-            run += (uint32_t)__builtin_amdgcn_readlane((int)incl[k], 63);
-        }
-        if (lane == 0u) wsum[buf][w] = run;
-        __syncthreads();
-        uint32_t before = 0u, total = 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < 16u; j++) { const uint32_t x = wsum[buf][j]; total += x; if (j < w) before += x; }
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) {
-            const uint32_t i = first + k * 64u;
-            if (i < n) off[i] = carry + before + row_before[k] + incl[k] - v[k];
-        }
-        carry += total;
-        buf ^= 1u; // the next batch's sums go to the other row: one barrier per batch is enough
+__global__ __launch_bounds__(1024) void k_plan_scatter(PlanArgs a) {
+    __shared__ uint32_t red[3][16];
+    __shared__ uint32_t cnt[2][RT_PLAN_BLOCK_RUNS];
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id(), b = blockIdx.x;
+    // the long and the other slots of the blocks before this one, and the long slots of all blocks
+    uint32_t sl = 0u, ss = 0u, tl = 0u;
+    for (uint32_t j = t; j < gridDim.x; j += 1024u) {
+        const uint2 v = reinterpret_cast<const uint2*>(a.block_sums)[j];
+        tl += v.x;
+        if (j < b) { sl += v.x; ss += v.y; }
     }
-    if (t == 0) off[n] = carry;
-}
-
-// a wave per run
-__global__ __launch_bounds__(256) void k_plan_scatter(PlanArgs a) {
-    const uint32_t run = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (run >= a.n_runs) return;
-    const uint32_t gid = (run << 6) | lane_id();
-    const uint32_t cls = plan_class(a.gen, gid, a.term_prob);
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += (uint32_t)__shfl_xor((int)sl, o, 64); ss += (uint32_t)__shfl_xor((int)ss, o, 64); tl += (uint32_t)__shfl_xor((int)tl, o, 64);
+    }
+    if (lane == 0) { red[0][w] = sl; red[1][w] = ss; red[2][w] = tl; }
+    if (t < RT_PLAN_BLOCK_RUNS) {
+        const uint32_t p = b * RT_PLAN_BLOCK_RUNS + t;
+        const uint2 v = p < a.n_runs ? reinterpret_cast<const uint2*>(a.counts)[p] : make_uint2(0u, 0u);
+        cnt[0][t] = v.x; cnt[1][t] = v.y;
+    }
+    __syncthreads();
+    sl = 0u; ss = 0u; tl = 0u;
 #pragma unroll
-    for (uint32_t c = 0; c < RT_PLAN_ITEMS; c++) {
-        const unsigned long long m = __ballot(cls == c);
-        if (cls == c) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            a.perm[a.offsets[plan_place(a, run, c)] + rank] = gid;
-        }
+    for (uint32_t k = 0; k < 16u; k++) { sl += red[0][k]; ss += red[1][k]; tl += red[2][k]; }
+    uint32_t bl = 0u, bs = 0u; // the places of this block before this wave's
+    for (uint32_t k = 0; k < w * RT_PLAN_WAVE_RUNS; k++) { bl += cnt[0][k]; bs += cnt[1][k]; }
+#pragma unroll
+    for (uint32_t i = 0; i < RT_PLAN_WAVE_RUNS; i++) {
+        const uint32_t q = w * RT_PLAN_WAVE_RUNS + i, p = b * RT_PLAN_BLOCK_RUNS + q;
+        if (p >= a.n_runs) break;
+        const uint32_t gid = (a.order[p] << 6) | lane;
+        const uint32_t cls = plan_class(a.gen, gid, a.term_prob);
+        const unsigned long long ml = __ballot(cls == 0u), ms = __ballot(cls == 1u);
+        const unsigned long long mine = cls == 0u ? ml : ms;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        uint32_t dst;
+        if (a.split) dst = cls == 0u ? sl + bl + rank : tl + ss + bs + rank;
+        else dst = sl + ss + bl + bs + (cls == 0u ? rank : cnt[0][q] + rank);
+        if (cls < 2u) a.perm[dst] = gid;
+        bl += cnt[0][q]; bs += cnt[1][q];
     }
 }

@@ -129,9 +129,9 @@ struct rthip_ctx {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* path_cost = nullptr;   // k_path: what each run of camera paths cost in the last short call, and the
-    uint32_t* path_rank = nullptr;   // place of each run in the order (expensive first) in which the next one hands them out
+    uint32_t* path_order = nullptr;  // the runs in the order (expensive first) in which the next one hands them out
     uint64_t  path_runs_cap = 0;
-    uint32_t* path_plan = nullptr;   // k_plan_*: per place, the count of its slots and the prefix of the counts
+    uint32_t* path_plan = nullptr;   // k_plan_*: per place and per block of places, the slots of either kind
     uint32_t* path_perm = nullptr;   // hand-out position -> queue slot (64 words per run)
     uint32_t  order_runs = 0, order_res_x = 0, order_res_y = 0, order_frames = 0, order_spread = 0; // what the order was made for (0 runs: none)
     uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
@@ -205,7 +205,7 @@ void free_work_buffers(rthip_ctx* c) {
     free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
     free_dev_t(c->cand_lists);
     free_dev_t(c->path_cost);
-    free_dev_t(c->path_rank);
+    free_dev_t(c->path_order);
     free_dev_t(c->path_plan);
     free_dev_t(c->path_perm);
     c->path_runs_cap = 0;
@@ -1158,7 +1158,6 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         const uint32_t gen_grid = (uint32_t)((slots + 255) / 256);
         const bool overwrite = (c->reject_hist == 1);
         const bool tap_group = taps && f0 == 0;
-        HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 512, c->stream));
         ga.out = q[0];
         ga.count_out = c->ctrl;
         ga.first_frame = first_frame + f0 * frame_stride;
@@ -1171,6 +1170,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk only.
         // (the bound was measured on 256 CUs; a partition of the chip gets its share of it)
         const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && c->watchdog_dev != nullptr;
+        // queue counts and cursors start at zero (the single launch has one cursor, which the kernels that make its hand-out order clear)
+        if (!(fused && lpt_env != 0)) HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 512, c->stream));
         if (fused) {
             PathArgs pa{};
             pa.sc = c->sc;
@@ -1228,36 +1229,36 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 if (c->path_runs_cap < n_runs) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     free_dev_t(c->path_cost);
-                    free_dev_t(c->path_rank);
+                    free_dev_t(c->path_order);
                     free_dev_t(c->path_plan);
                     free_dev_t(c->path_perm);
                     c->path_runs_cap = 0;
                     c->order_runs = 0;
                     HIP_TRY(c, hipMalloc((void**)&c->path_cost, sizeof(uint32_t) * n_runs));
-                    HIP_TRY(c, hipMalloc((void**)&c->path_rank, sizeof(uint32_t) * (size_t)n_runs));
-                    HIP_TRY(c, hipMalloc((void**)&c->path_plan, sizeof(uint32_t) * (2 * RT_PLAN_ITEMS * (size_t)n_runs + 1)));
+                    HIP_TRY(c, hipMalloc((void**)&c->path_order, sizeof(uint32_t) * (size_t)n_runs));
+                    HIP_TRY(c, hipMalloc((void**)&c->path_plan, sizeof(uint32_t) * (2 * (size_t)n_runs + 2 * ((size_t)n_runs / RT_PLAN_BLOCK_RUNS + 1))));
                     HIP_TRY(c, hipMalloc((void**)&c->path_perm, sizeof(uint32_t) * 64 * (size_t)n_runs));
                     c->path_runs_cap = n_runs;
                 }
                 const bool same = c->order_runs == n_runs && c->order_res_x == c->res_x && c->order_res_y == c->res_y && c->order_frames == nf &&
                                   c->order_spread == pa.gen.spread_shift && !overwrite;
                 if (!same) {
-                    hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_rank, n_runs);
+                    hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_order, n_runs);
                     c->order_runs = n_runs; c->order_res_x = c->res_x; c->order_res_y = c->res_y; c->order_frames = nf; c->order_spread = pa.gen.spread_shift;
                 }
                 PlanArgs pl{};
                 pl.gen = pa.gen;
-                pl.rank = c->path_rank;
-                pl.split = split;
+                pl.order = c->path_order;
                 pl.n_runs = n_runs;
+                pl.split = split;
                 pl.term_prob = P.term_prob;
                 pl.counts = c->path_plan;
-                pl.offsets = c->path_plan + RT_PLAN_ITEMS * (size_t)n_runs;
+                pl.block_sums = c->path_plan + 2 * (size_t)n_runs;
                 pl.perm = c->path_perm;
-                const uint32_t plan_grid = (n_runs + 3u) / 4u;
-                hipLaunchKernelGGL(k_plan_count, dim3(plan_grid), dim3(256), 0, c->stream, pl);
-                hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)pl.counts, pl.offsets, RT_PLAN_ITEMS * n_runs);
-                hipLaunchKernelGGL(k_plan_scatter, dim3(plan_grid), dim3(256), 0, c->stream, pl);
+                pl.cursor = pa.cursor;
+                const uint32_t plan_grid = (n_runs + RT_PLAN_BLOCK_RUNS - 1u) / RT_PLAN_BLOCK_RUNS;
+                hipLaunchKernelGGL(k_plan_count, dim3(plan_grid), dim3(1024), 0, c->stream, pl);
+                hipLaunchKernelGGL(k_plan_scatter, dim3(plan_grid), dim3(1024), 0, c->stream, pl);
                 pa.perm = c->path_perm;
                 pa.cost = c->path_cost;
                 pa.n_slots = (uint32_t)(c->n_pixels * nf); // the slots that are inside the image
@@ -1291,7 +1292,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
                                    (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
             }
-            if (pa.cost) hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, c->stream, c->path_cost, c->path_rank, n_runs);
+            if (pa.cost) hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, c->stream, c->path_cost, c->path_order, n_runs);
             c->reject_hist = 0; // main.rs:403
             if (tap_group) c->taps_valid = true;
             continue;
