@@ -82,6 +82,38 @@ def test_short_path_equals_staged_pipeline_bit_for_bit(ctx, scenes, name, sun):
     assert (ref_cnt["shadow_rays"] > 0) == (sun == 1)
 
 
+@pytest.mark.parametrize("knobs", [dict(RTHIP_PATH_SPLIT="1"), dict(RTHIP_PATH_SPLIT="0"), dict(RTHIP_PATH_LONGEST_FIRST="0"),
+                                   dict(RTHIP_PATH_SPLIT="1", RTHIP_SPREAD="2")])
+def test_hand_out_order_changes_no_result(ctx, scenes, knobs):
+    """The single launch hands its camera paths out in an order made from the costs of the call
+    before and from every path's first termination draw (long paths first where a lane gets many
+    paths).  On these small images the library would keep every run's paths together: the knobs
+    force each form, on images whose edge tiles are partly outside (67 x 41) and with several frames
+    per call -- every pixel must get each of its samples exactly once, and the sums must not move."""
+    import os
+    for name in ("box", "materials"):
+        s, a, res = scenes[name]
+        ctx.upload_scene(a)
+        calls = [(1, 1), (2, 1), (3, 3), (6, 1)]
+        ref_acc, ref_taps, ref_cnt = render(ctx, s, res, calls, flags=device.FLAG_STAGED, max_bounces=6)
+        old = {k: os.environ.get(k) for k in knobs}
+        try:
+            os.environ.update(knobs)
+            acc, taps, cnt = render(ctx, s, res, calls, max_bounces=6)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert np.all(acc[..., 3] == 6.0), (name, knobs)
+        assert np.array_equal(acc, ref_acc), (name, knobs)
+        for k in ("tri", "prim", "t", "seed"):
+            assert np.array_equal(taps[k], ref_taps[k]), (name, knobs, k)
+        for k in EXACT:
+            assert cnt[k] == ref_cnt[k], (name, knobs, k, cnt[k], ref_cnt[k])
+
+
 def test_short_path_is_the_one_that_runs(ctx, scenes):
     """Timing records which launches a call made: a frame group of at most 8 * 2^20 camera paths =
     one k_path launch and no stage launch (15 360 per frame here: any group); more = the staged
