@@ -134,6 +134,11 @@ struct rthip_ctx {
     uint32_t* path_plan = nullptr;   // k_plan_*: per place and per block of places, the slots of either kind
     uint32_t* path_perm = nullptr;   // hand-out position -> queue slot (64 words per run)
     uint32_t  order_runs = 0, order_res_x = 0, order_res_y = 0, order_frames = 0, order_spread = 0; // what the order was made for (0 runs: none)
+    // k_order_runs prepares the NEXT call of the single launch, so it runs on a stream of its own
+    // behind the launch: the caller's synchronisation does not wait for it, the next call's kernels do
+    hipStream_t side_stream = nullptr;
+    hipEvent_t  ev_path_done = nullptr, ev_order_done = nullptr;
+    bool      order_pending = false;
     uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
     uint32_t* watchdog_dev = nullptr;  // the same word as the device sees it
     unsigned char* noalloc_scratch = nullptr; // this device's copy of `scratch` (rthip_trace_rays_noalloc)
@@ -202,6 +207,8 @@ void free_scene(rthip_ctx* c) {
 
 // the per-frame work buffers: everything sized by the 8x8-tile slot count or the frame group
 void free_work_buffers(rthip_ctx* c) {
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream); // k_order_runs may still be reading the buffers freed below
+    c->order_pending = false;
     free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
     free_dev_t(c->cand_lists);
     free_dev_t(c->path_cost);
@@ -515,6 +522,9 @@ void rthip_destroy(rthip_ctx* c) {
     free_scene(c);
     free_frame_buffers(c);
     free_dev_t(c->ctrl);
+    if (c->ev_path_done) (void)hipEventDestroy(c->ev_path_done);
+    if (c->ev_order_done) (void)hipEventDestroy(c->ev_order_done);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     free_dev_t(c->d_counters);
     if (c->watchdog_host) (void)hipHostFree(c->watchdog_host);
     free_dev_t(c->tr_q); free_dev_t(c->tr_hits); free_dev_t(c->tr_lists); free_dev_t(c->resolve_out);
@@ -1226,6 +1236,10 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             uint32_t split = slots >= 6ull * 256ull * pgrid ? 1u : 0u;
             if (split_env >= 0) split = split_env ? 1u : 0u;
             if (lpt_env != 0) {
+                if (c->order_pending) { // the order this call hands out by is still being made
+                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_order_done, 0));
+                    c->order_pending = false;
+                }
                 if (c->path_runs_cap < n_runs) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     free_dev_t(c->path_cost);
@@ -1292,7 +1306,28 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 hipLaunchKernelGGL(k_accumulate, dim3(acc_grid), dim3(256), 0, c->stream, c->accum, (const float4*)c->partial,
                                    (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
             }
-            if (pa.cost) hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, c->stream, c->path_cost, c->path_order, n_runs);
+            if (pa.cost) {
+                // the order of the next call: behind this launch, beside whatever the caller does next
+                if (!c->side_stream) {
+                    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->ev_path_done, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->ev_order_done, hipEventDisableTiming) != hipSuccess) {
+                        (void)hipGetLastError();
+                        if (c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
+                    }
+                }
+                hipStream_t os = c->stream;
+                if (c->side_stream && c->ev_path_done && c->ev_order_done) {
+                    HIP_TRY(c, hipEventRecord(c->ev_path_done, c->stream));
+                    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_path_done, 0));
+                    os = c->side_stream;
+                }
+                hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, os, c->path_cost, c->path_order, n_runs);
+                if (os != c->stream) {
+                    HIP_TRY(c, hipEventRecord(c->ev_order_done, os));
+                    c->order_pending = true;
+                }
+            }
             c->reject_hist = 0; // main.rs:403
             if (tap_group) c->taps_valid = true;
             continue;
