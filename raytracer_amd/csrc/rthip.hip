@@ -138,7 +138,7 @@ struct rthip_ctx {
     // behind the launch: the caller's synchronisation does not wait for it, the next call's kernels do
     hipStream_t side_stream = nullptr;
     hipEvent_t  ev_path_done = nullptr, ev_order_done = nullptr;
-    bool      order_pending = false;
+    bool      order_pending = false, side_failed = false;
     uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
     uint32_t* watchdog_dev = nullptr;  // the same word as the device sees it
     unsigned char* noalloc_scratch = nullptr; // this device's copy of `scratch` (rthip_trace_rays_noalloc)
@@ -1236,6 +1236,17 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             uint32_t split = slots >= 6ull * 256ull * pgrid ? 1u : 0u;
             if (split_env >= 0) split = split_env ? 1u : 0u;
             if (lpt_env != 0) {
+                // (the second stream is made before anything of this call is launched: a queue that
+                // appears while a persistent kernel runs had that kernel's first launch take 10 ms instead of 3)
+                if (!c->side_stream && !c->side_failed) {
+                    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->ev_path_done, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->ev_order_done, hipEventDisableTiming) != hipSuccess) {
+                        (void)hipGetLastError();
+                        if (c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
+                        c->side_failed = true;
+                    }
+                }
                 if (c->order_pending) { // the order this call hands out by is still being made
                     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_order_done, 0));
                     c->order_pending = false;
@@ -1308,14 +1319,6 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             }
             if (pa.cost) {
                 // the order of the next call: behind this launch, beside whatever the caller does next
-                if (!c->side_stream) {
-                    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&c->ev_path_done, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&c->ev_order_done, hipEventDisableTiming) != hipSuccess) {
-                        (void)hipGetLastError();
-                        if (c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
-                    }
-                }
                 hipStream_t os = c->stream;
                 if (c->side_stream && c->ev_path_done && c->ev_order_done) {
                     HIP_TRY(c, hipEventRecord(c->ev_path_done, c->stream));
