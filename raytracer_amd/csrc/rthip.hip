@@ -1103,6 +1103,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     if (const char* e = knob(c, "RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
     bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
     if (const char* e = knob(c, "RTHIP_FORCE_STAGED")) staged_only = staged_only || std::atoi(e) != 0; // tests: a whole module through the staged pipeline
+    int keep_env = 1;
+    if (const char* e = knob(c, "RTHIP_PATH_KEEP_ORDER")) keep_env = std::atoi(e); // experiment knob: 0 = a call that discards the image starts from the plain order
     int split_env = -1;
     if (const char* e = knob(c, "RTHIP_PATH_SPLIT")) split_env = std::atoi(e); // experiment knob: 1 / 0 = long paths of all runs first / every run's paths together
     int lpt_env = 1;
@@ -1229,8 +1231,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             }
             // Hand-out order (rt_path.h): the camera paths of expensive tiles first, and of every tile
             // first those that outlive their first termination draw, by what the runs cost in the
-            // last call of this shape (resolution, frames per call).  A new shape, a new scene or a
-            // discarded history (reject_hist: the view has changed) starts without costs.
+            // last call of this shape (resolution, frames per call).  A new shape or a new scene starts
+            // without costs.
             const uint32_t n_runs = (uint32_t)(slots >> 6);
             // long paths of all runs first where a lane gets six camera paths or more (measured: 1080p and up on 256 CUs)
             uint32_t split = slots >= 6ull * 256ull * pgrid ? 1u : 0u;
@@ -1265,8 +1267,10 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                     HIP_TRY(c, hipMalloc((void**)&c->path_perm, sizeof(uint32_t) * 64 * (size_t)n_runs));
                     c->path_runs_cap = n_runs;
                 }
+                // (a call that discards the image keeps the order: while the camera moves every call
+                // discards, and what the tiles cost one frame ago still says more than nothing)
                 const bool same = c->order_runs == n_runs && c->order_res_x == c->res_x && c->order_res_y == c->res_y && c->order_frames == nf &&
-                                  c->order_spread == pa.gen.spread_shift && !overwrite;
+                                  c->order_spread == pa.gen.spread_shift && (keep_env != 0 || !overwrite);
                 if (!same) {
                     hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_order, n_runs);
                     c->order_runs = n_runs; c->order_res_x = c->res_x; c->order_res_y = c->res_y; c->order_frames = nf; c->order_spread = pa.gen.spread_shift;
