@@ -148,7 +148,7 @@ int rthip_render(rthip_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32
 int rthip_reserve(rthip_ctx* ctx, uint32_t n_frames);
 
 /* How many frames the next rthip_render would move through the stages together at the current
- * resolution: RTHIP_FRAMES_IN_FLIGHT (default 64), lowered until the work buffers (160 bytes per
+ * resolution: RTHIP_FRAMES_IN_FLIGHT (default 128), lowered until the work buffers (160 bytes per
  * path slot) fit 96 GiB and half of the device memory that is free -- a limit that is otherwise
  * applied silently.  No counterpart upstream. */
 int rthip_frames_in_flight(rthip_ctx* ctx, uint32_t* n_frames);

@@ -272,7 +272,7 @@ bool invert4(const double m[16], double out[16]) {
 #define RT_QUEUE_BUDGET_GIB 96
 #endif
 uint32_t frames_in_flight_limit(const rthip_ctx* c) {
-    uint32_t want = 64;
+    uint32_t want = 128; // 64 / 96 / 128 frames per group at 1080p: 2793 / 2827 / 2840 Mrays/s (the launches' tails weigh half as much)
     if (const char* e = knob(c, "RTHIP_FRAMES_IN_FLIGHT")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 128) want = (uint32_t)v;

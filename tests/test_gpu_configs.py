@@ -125,7 +125,7 @@ def test_config3_atrium_1080p_whole_frames_match_oracle(ctx, atrium):
 
 
 def test_config3_frame_grouping_is_invisible(ctx, atrium):
-    """72 frames in one call (groups of 64 + 8), in groups of 7, and one frame per call give the
+    """72 frames in one call (one group), in groups of 7, and one frame per call give the
     same accumulator bit for bit; so does a second run."""
     s, a = atrium
     res = (1920, 1080)

@@ -122,14 +122,14 @@ def test_short_path_is_the_one_that_runs(ctx, scenes):
     ctx.upload_scene(a)
     ctx.set_frame_uniforms(s.frame_uniforms(res, frame=1, reject_hist=1))
     p = device.default_params(flags=device.FLAG_TIMING)
-    for n in (1, 2, 3, 4, 64):
+    for n in (1, 2, 3, 4, 64, 128):
         ctx.reset_timing()
         ctx.render(1, n, 1, p)
         t = ctx.timing()
         assert t["path"]["launches"] == 1, (n, t)
         assert t["extend"]["launches"] == 0, (n, t)
     ctx.reset_timing()
-    ctx.render(1, 65, 1, p)          # two frame groups (64 frames in flight): two launches
+    ctx.render(1, 129, 1, p)         # two frame groups (128 frames in flight): two launches
     assert ctx.timing()["path"]["launches"] == 2
     ctx.set_frame_uniforms(s.frame_uniforms((1920, 1080), frame=1, reject_hist=1))
     for n, want_path in ((4, 1), (5, 0)):

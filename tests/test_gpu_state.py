@@ -147,11 +147,11 @@ def test_frames_in_flight_reports_the_group_size_in_use(monkeypatch):
         with pytest.raises(device.RtHipError, match="set_frame_uniforms first"):
             c.frames_in_flight()
         c.set_frame_uniforms(s.frame_uniforms((1920, 1080), frame=1, reject_hist=1))
-        assert c.frames_in_flight() == 64
+        assert c.frames_in_flight() == 128
         c.set_frame_uniforms(s.frame_uniforms((3840, 2160), frame=1, reject_hist=1))
-        assert c.frames_in_flight() == 64               # 85 GB of work buffers: within the 96 GiB (and half of the free memory)
+        assert 64 <= c.frames_in_flight() < 128         # 96 GiB of work buffers at most (and half of the free memory)
         c.set_frame_uniforms(s.frame_uniforms((7680, 4320), frame=1, reject_hist=1))
-        assert 8 <= c.frames_in_flight() < 32           # 96 GiB of work buffers at most
+        assert 8 <= c.frames_in_flight() < 32
         monkeypatch.setenv("RTHIP_FRAMES_IN_FLIGHT", "7")
         assert c.frames_in_flight() == 7
     finally:
