@@ -72,6 +72,7 @@ struct GenArgs {
     uint32_t  first_frame, frame_stride, n_frames; // frames first, first + stride, ... share this launch
     uint32_t  n_pixels;
     uint32_t  spread_shift;       // 0: a run of 64 slots is one 8x8 tile; 2: four 4x4 blocks of four far-apart tiles; 4: sixteen 2x2 blocks
+    const uint32_t* tile_order;   // not null (staged pipeline, spread_shift 0): the tiles of the queue in this order (a permutation of the tiles)
     unsigned long long* counters; // may be null
 };
 
@@ -91,8 +92,9 @@ __device__ __forceinline__ bool slot_pixel(const GenArgs& a, uint32_t gid, uint3
     // runs of 64 slots hold rays through the same pixels (and stay neighbours through the
     // order-preserving compaction of the later bounces)
     const uint32_t run = gid >> 6, l = gid & 63u;
-    const uint32_t tile = run / a.n_frames;
+    uint32_t tile = run / a.n_frames;
     fs = run - tile * a.n_frames;
+    if (a.tile_order) tile = a.tile_order[tile];
     // Which pixel of which tile lane l of the run renders.  A whole tile per run keeps a wave's
     // rays together (they walk the same nodes), and with it their cost: the rays of a tile full of
     // foliage all take several times the average, and the wave that holds them ends long after the

@@ -133,6 +133,8 @@ struct rthip_ctx {
     uint64_t  path_runs_cap = 0;
     uint32_t* path_plan = nullptr;   // k_plan_*: per place and per block of places, the slots of either kind
     uint32_t* path_perm = nullptr;   // hand-out position -> queue slot (64 words per run)
+    uint32_t* tile_order = nullptr;  // the staged pipeline's copy of the order a one-frame single launch left behind (tiles, expensive first)
+    uint32_t  tile_order_cap = 0, tile_order_tiles = 0, tile_order_res_x = 0, tile_order_res_y = 0; // 0 tiles: none
     uint32_t  order_runs = 0, order_res_x = 0, order_res_y = 0, order_frames = 0, order_spread = 0; // what the order was made for (0 runs: none)
     // k_order_runs prepares the NEXT call of the single launch, so it runs on a stream of its own
     // behind the launch: the caller's synchronisation does not wait for it, the next call's kernels do
@@ -215,6 +217,9 @@ void free_work_buffers(rthip_ctx* c) {
     free_dev_t(c->path_order);
     free_dev_t(c->path_plan);
     free_dev_t(c->path_perm);
+    free_dev_t(c->tile_order);
+    c->tile_order_cap = 0;
+    c->tile_order_tiles = 0;
     c->path_runs_cap = 0;
     c->order_runs = 0;
     c->cand_cap = 0;
@@ -998,6 +1003,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->have_scene = true;
     c->reject_hist = 1;
     c->order_runs = 0; // what the runs of camera paths cost in the old scene says nothing about this one
+    c->tile_order_tiles = 0;
     return RTHIP_OK;
 }
 
@@ -1109,6 +1115,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     if (const char* e = knob(c, "RTHIP_PATH_BLOCKS_PER_CU")) path_blocks_env = std::atoi(e);
     bool staged_only = (P.flags & RTHIP_FLAG_STAGED) != 0;
     if (const char* e = knob(c, "RTHIP_FORCE_STAGED")) staged_only = staged_only || std::atoi(e) != 0; // tests: a whole module through the staged pipeline
+    int tile_lpt_env = 1;
+    if (const char* e = knob(c, "RTHIP_STAGED_TILE_ORDER")) tile_lpt_env = std::atoi(e); // experiment knob: 0 = the staged pipeline queues its tiles as they lie in the image
     int keep_env = 1;
     if (const char* e = knob(c, "RTHIP_PATH_KEEP_ORDER")) keep_env = std::atoi(e); // experiment knob: 0 = a call that discards the image starts from the plain order
     int split_env = -1;
@@ -1138,8 +1146,23 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         if (v > 0 && v <= 16) { ext_blocks = v; ext_blocks_fixed = true; }
     }
 
-    for (uint32_t f0 = 0; f0 < n_frames; f0 += group) {
-        const uint32_t nf = std::min(group, n_frames - f0);
+    // The staged pipeline queues its tiles in the order of what they cost when the single launch last
+    // rendered one frame of this shape (expensive first: the last rays of every bounce's queue are then
+    // cheap ones, and the extend launches end sooner after their queues do: 20 frames 28.5 -> 27.9 ms,
+    // 64 frames 84.8 -> 84.3).  A call that would go through the staged pipeline and finds no such
+    // order renders its first frame as a single launch, which leaves one behind.
+    auto have_tile_order = [&]() {
+        return c->tile_order != nullptr && c->tile_order_tiles == ga.n_tiles && c->tile_order_res_x == c->res_x && c->tile_order_res_y == c->res_y;
+    };
+    const uint64_t path_max_slots = (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u;
+    const bool tile_order_wanted = tile_lpt_env != 0 && lpt_env != 0 && spread_env <= 0 && !staged_only && !multi && c->watchdog_dev != nullptr;
+    uint32_t nf = 0;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += nf) {
+        nf = std::min(group, n_frames - f0);
+        if (tile_order_wanted && nf > 1u && (uint64_t)ga.n_tiles * 64 * nf > path_max_slots && (uint64_t)ga.n_tiles * 64 <= path_max_slots && !have_tile_order()) {
+            nf = 1u;
+            // (what is left of the call then runs as it would have: staged, unless it has become small enough for the single launch)
+        }
         const uint64_t slots = (uint64_t)ga.n_tiles * 64 * nf;
         // A call of one to three frames does not fill the resident waves of the chip with rays (one
         // 1080p frame: four camera rays per lane, fewer in every bounce after): fewer, fuller waves
@@ -1187,13 +1210,14 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         // (rt_path.h): the staged pipeline below would spend most of such a call in the tails of its
         // per-bounce launches.  Same code per path, same results; scenes of one candidate chunk only.
         // (the bound was measured on 256 CUs; a partition of the chip gets its share of it)
-        const bool fused = !staged_only && slots <= (uint64_t)RT_PATH_MAX_SLOTS * (uint64_t)c->n_cu / 256u && !multi && c->watchdog_dev != nullptr;
+        const bool fused = !staged_only && slots <= path_max_slots && !multi && c->watchdog_dev != nullptr;
         // queue counts and cursors start at zero (the single launch has one cursor, which the kernels that make its hand-out order clear)
         if (!(fused && lpt_env != 0)) HIP_TRY(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * 512, c->stream));
         if (fused) {
             PathArgs pa{};
             pa.sc = c->sc;
             pa.gen = ga;
+            pa.gen.tile_order = nullptr; // the single launch has its own list (perm)
             pa.gen.spread_shift = (ga.n_tiles >= 64u && spread_env > 0) ? (spread_env == 4 ? 4u : 2u) : 0u;
             pa.gen.counters = nullptr;
             pa.cursor = c->ctrl + 64;
@@ -1254,6 +1278,14 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                         if (c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
                         c->side_failed = true;
                     }
+                }
+                if (nf == 1u && pa.gen.spread_shift == 0u && c->tile_order_cap < n_runs) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (c->side_stream) HIP_TRY(c, hipStreamSynchronize(c->side_stream));
+                    free_dev_t(c->tile_order);
+                    c->tile_order_cap = 0; c->tile_order_tiles = 0;
+                    HIP_TRY(c, hipMalloc((void**)&c->tile_order, sizeof(uint32_t) * n_runs));
+                    c->tile_order_cap = n_runs;
                 }
                 if (c->order_pending) { // the order this call hands out by is still being made
                     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_order_done, 0));
@@ -1336,6 +1368,11 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                     os = c->side_stream;
                 }
                 hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, os, c->path_cost, c->path_order, n_runs);
+                if (nf == 1u && pa.gen.spread_shift == 0u && c->tile_order != nullptr && c->tile_order_cap >= n_runs) {
+                    // one frame, whole tiles: the order of the runs is an order of the tiles; the staged pipeline keeps a copy
+                    HIP_TRY(c, hipMemcpyAsync(c->tile_order, c->path_order, sizeof(uint32_t) * n_runs, hipMemcpyDeviceToDevice, os));
+                    c->tile_order_tiles = n_runs; c->tile_order_res_x = c->res_x; c->tile_order_res_y = c->res_y;
+                }
                 if (os != c->stream) {
                     HIP_TRY(c, hipEventRecord(c->ev_order_done, os));
                     c->order_pending = true;
@@ -1344,6 +1381,14 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             c->reject_hist = 0; // main.rs:403
             if (tap_group) c->taps_valid = true;
             continue;
+        }
+        ga.tile_order = nullptr;
+        if (tile_order_wanted && ga.spread_shift == 0u && have_tile_order()) {
+            if (c->order_pending) {
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_order_done, 0));
+                c->order_pending = false;
+            }
+            ga.tile_order = c->tile_order;
         }
         {
             StageTimer t(c, timing, RTHIP_STAGE_GENERATE);
