@@ -245,3 +245,32 @@ def test_short_path_into_a_bound_accumulator_and_after_resize(ctx, scenes):
         acc1, _, _ = render(ctx, s, r, [(1, 1), (2, 1)])
         acc0, _, _ = render(ctx, s, r, [(1, 2)], flags=device.FLAG_STAGED)
         assert np.array_equal(acc0, acc1)
+
+
+def test_staged_pipeline_queues_tiles_by_cost_without_changing_a_bit(ctx, scenes):
+    """A group too large for the single launch goes through the staged pipeline with its tiles queued
+    expensive first, by the costs a one-frame single launch left behind; a large call that finds none
+    for its image renders its first frame that way.  Against RTHIP_FLAG_STAGED (tiles as they lie in
+    the image): the same bits, on images whose edge tiles are partly outside, and across changes of
+    resolution, after which the order of the old image must not be used."""
+    s, a, _ = scenes["atrium"]
+    ctx.upload_scene(a)
+    frames = 18                                            # 17 x 1003 x 517 > 8 * 2^20 camera paths: staged even after a first frame on its own
+    sizes = ((1003, 517), (1100, 480), (1003, 517))
+    want = {}
+    for res in sizes[:2]:
+        want[res] = render(ctx, s, res, [(1, frames)], flags=device.FLAG_STAGED, max_bounces=4)
+    for res, again in ((sizes[0], False), (sizes[0], True), (sizes[1], False), (sizes[2], False)):
+        ctx.reset_timing()
+        acc, taps, cnt = render(ctx, s, res, [(1, frames)], flags=device.FLAG_TIMING, max_bounces=4)
+        t = ctx.timing()
+        # the first large call at a resolution: one frame as a single launch, the rest staged
+        assert t["path"]["launches"] == (0 if again else 1), (res, again, t)
+        assert t["extend"]["launches"] == 4, (res, again, t)
+        ref_acc, ref_taps, ref_cnt = want[res]
+        assert np.all(acc[..., 3] == float(frames))
+        assert np.array_equal(acc, ref_acc), (res, again)
+        for k in ("tri", "prim", "t", "seed"):
+            assert np.array_equal(taps[k], ref_taps[k]), (res, again, k)
+        for k in EXACT:
+            assert cnt[k] == ref_cnt[k], (res, again, k, cnt[k], ref_cnt[k])
