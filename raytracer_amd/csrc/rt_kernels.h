@@ -381,16 +381,37 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // k_cull for those primitives only.  The interval test is
 // conservative: its bounds are widened beyond f32 rounding, and an axis on which the directions
 // straddle (or come close to) zero puts no constraint.  The masks are those k_cull computes.
-__global__ __launch_bounds__(256) void k_cull_camera(CullArgs a) {
-    const uint32_t n = *a.count_in;
+// GENERATE: the rays are not read from the queue but made here, as k_generate makes them (g says
+// how), and written to it: one launch and one pass over the queue less.
+template <bool GENERATE>
+__global__ __launch_bounds__(256) void k_cull_camera(CullArgs a, GenArgs g) {
+    const uint32_t n = GENERATE ? g.n_tiles * 64u * g.n_frames : *a.count_in;
     const SceneDev& sc = a.sc;
     const uint32_t lane = lane_id();
     const float inf = __builtin_inff();
+    if (GENERATE && blockIdx.x == 0 && threadIdx.x == 0) *g.count_out = n;
     for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < n; base += gridDim.x * blockDim.x) {
         const uint32_t slot = base + lane;
         f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
         bool live = false;
-        if (slot < n) {
+        if (GENERATE) { // whole runs of 64: slot < n
+            uint32_t seed = 0, pix = RT_NO_PIXEL;
+            f3 co, cd;
+            live = camera_path(g, slot, co, cd, seed, pix);
+            float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, __uint_as_float(RT_NO_PIXEL));
+            if (live) {
+                o = co;
+                d = cd;
+                s0 = make_float4(o.x, o.y, o.z, d.x);
+                s1 = make_float4(d.y, d.z, __uint_as_float(seed), __uint_as_float(pix));
+            }
+            g.out.s0[slot] = s0;
+            g.out.s1[slot] = s1;
+            if (g.counters) {
+                const unsigned long long np = wave_sum(live ? 1ull : 0ull);
+                if (lane == 0 && np) atomicAdd(&g.counters[C_PATHS], np);
+            }
+        } else if (slot < n) {
             const float4 s0 = a.in.s0[slot], s1 = a.in.s1[slot];
             live = __float_as_uint(s1.w) != RT_NO_PIXEL;
             o = F3(s0.x, s0.y, s0.z);

@@ -1139,6 +1139,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
     const bool cull = !multi && c->sc.n_prims > RT_CULL_MIN_PRIMS;
     bool cull_camera = true;
     if (const char* e = knob(c, "RTHIP_CULL_CAMERA")) cull_camera = std::atoi(e) != 0; // diagnostic: 0 = the general cull kernel for camera rays too
+    bool fuse_generate = true;
+    if (const char* e = knob(c, "RTHIP_GENERATE_IN_CULL")) fuse_generate = std::atoi(e) != 0; // experiment knob: 0 = k_generate, then the camera cull
     int ext_blocks = extend_occupancy(count, deep, ext_mode);
     bool ext_blocks_fixed = false;
     if (const char* e = knob(c, "RTHIP_EXTEND_BLOCKS_PER_CU")) { // tuning knob; the default comes from the occupancy query
@@ -1390,7 +1392,9 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
             }
             ga.tile_order = c->tile_order;
         }
-        {
+        // camera rays and their candidate masks in one launch where the camera cull runs at all
+        const bool generate_in_cull = cull && cull_camera && fuse_generate && P.max_bounces > 0u;
+        if (!generate_in_cull) {
             StageTimer t(c, timing, RTHIP_STAGE_GENERATE);
             hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(256), 0, c->stream, ga);
         }
@@ -1427,7 +1431,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 ca.count_in = c->ctrl + b;
                 StageTimer t(c, timing, RTHIP_STAGE_CULL);
                 // camera rays: a wave's slots are one pixel tile, whose rays meet few primitives
-                if (b == 0 && cull_camera) hipLaunchKernelGGL(k_cull_camera, dim3(shade_grid), dim3(256), 0, c->stream, ca);
+                if (b == 0 && generate_in_cull) hipLaunchKernelGGL(k_cull_camera<true>, dim3(shade_grid), dim3(256), 0, c->stream, ca, ga);
+                else if (b == 0 && cull_camera) hipLaunchKernelGGL(k_cull_camera<false>, dim3(shade_grid), dim3(256), 0, c->stream, ca, ga);
                 else hipLaunchKernelGGL(k_cull, dim3(shade_grid), dim3(256), 0, c->stream, ca);
             }
             if (ext_mode == EXT_LIST) {

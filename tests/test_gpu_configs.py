@@ -298,24 +298,31 @@ def test_camera_cull_gives_the_masks_of_the_general_cull(ctx, atrium):
     p = device.default_params(max_bounces=2)
     p.flags |= device.FLAG_COUNTERS | device.FLAG_TAPS
     out = {}
-    old = os.environ.get("RTHIP_CULL_CAMERA")
+    # general cull / camera cull that also makes the camera rays (the default) / camera cull behind k_generate
+    modes = {"0": dict(RTHIP_CULL_CAMERA="0"), "1": dict(RTHIP_CULL_CAMERA="1"), "2": dict(RTHIP_CULL_CAMERA="1", RTHIP_GENERATE_IN_CULL="0")}
+    names = ("RTHIP_CULL_CAMERA", "RTHIP_GENERATE_IN_CULL")
+    old = {k: os.environ.get(k) for k in names}
     try:
-        for mode in ("0", "1"):
-            os.environ["RTHIP_CULL_CAMERA"] = mode
+        for mode, env in modes.items():
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(env)
             ctx.upload_scene(a)
             ctx.set_frame_uniforms(s.frame_uniforms(res, frame=3, reject_hist=1))
             ctx.reset_counters()
             ctx.render(3, 6, 1, p)
             out[mode] = (ctx.read_accum(), ctx.counters(), ctx.read_taps())
     finally:
-        if old is None:
-            del os.environ["RTHIP_CULL_CAMERA"]
-        else:
-            os.environ["RTHIP_CULL_CAMERA"] = old
-    for k in ("rays", "prims_visited", "inner_steps", "tri_tests", "alpha_tests", "misses"):
-        assert out["0"][1][k] == out["1"][1][k], k
-    assert np.array_equal(out["0"][0], out["1"][0])
-    assert np.array_equal(out["0"][2]["tri"], out["1"][2]["tri"])
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for mode in ("1", "2"):
+        for k in ("rays", "paths", "prims_visited", "inner_steps", "tri_tests", "alpha_tests", "misses"):
+            assert out["0"][1][k] == out[mode][1][k], (mode, k)
+        assert np.array_equal(out["0"][0], out[mode][0]), mode
+        assert np.array_equal(out["0"][2]["tri"], out[mode][2]["tri"]), mode
 
 
 @pytest.mark.parametrize("walk", ["scan", "pyramid", "list"])
