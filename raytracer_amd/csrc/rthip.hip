@@ -128,19 +128,30 @@ struct rthip_ctx {
 
     unsigned long long* d_counters = nullptr;
 
-    uint32_t* path_cost = nullptr;   // k_path: what each run of camera paths cost in the last short call, and the
-    uint32_t* path_order = nullptr;  // the runs in the order (expensive first) in which the next one hands them out
+    // k_path: what each run of camera paths cost in a call of the single launch, and the runs in the
+    // order (expensive first) made from that.  Two sets, used in turn: a call hands out by the order
+    // that is ready -- the one the call before left if that has been made by now, else the one of the
+    // call before that -- and never waits for k_order_runs of the call before while it has an older one.
+    struct OrderSet {
+        uint32_t* cost = nullptr;    // zero between calls (k_order_runs clears what it has read)
+        uint32_t* order = nullptr;
+        uint32_t  runs = 0, res_x = 0, res_y = 0, frames = 0, spread = 0; // what the order was made for (0 runs: none)
+        hipEvent_t done = nullptr;   // the k_order_runs that writes this set has finished
+        bool      pending = false;   // ... and the stream of the calls has not been told to wait for it yet
+    };
+    OrderSet  oset[2];
+    uint32_t  oset_turn = 0;         // the set the next call of the single launch writes
+    uint32_t  tile_order_set = 0;    // the set whose k_order_runs the copy in tile_order follows
     uint64_t  path_runs_cap = 0;
     uint32_t* path_plan = nullptr;   // k_plan_*: per place and per block of places, the slots of either kind
     uint32_t* path_perm = nullptr;   // hand-out position -> queue slot (64 words per run)
     uint32_t* tile_order = nullptr;  // the staged pipeline's copy of the order a one-frame single launch left behind (tiles, expensive first)
     uint32_t  tile_order_cap = 0, tile_order_tiles = 0, tile_order_res_x = 0, tile_order_res_y = 0; // 0 tiles: none
-    uint32_t  order_runs = 0, order_res_x = 0, order_res_y = 0, order_frames = 0, order_spread = 0; // what the order was made for (0 runs: none)
     // k_order_runs prepares the NEXT call of the single launch, so it runs on a stream of its own
     // behind the launch: the caller's synchronisation does not wait for it, the next call's kernels do
     hipStream_t side_stream = nullptr;
-    hipEvent_t  ev_path_done = nullptr, ev_order_done = nullptr;
-    bool      order_pending = false, side_failed = false;
+    hipEvent_t  ev_path_done = nullptr;
+    bool      side_failed = false;
     uint32_t* watchdog_host = nullptr; // pinned host word that a kernel sets when one of its bounded loops ran out
     uint32_t* watchdog_dev = nullptr;  // the same word as the device sees it
     unsigned char* noalloc_scratch = nullptr; // this device's copy of `scratch` (rthip_trace_rays_noalloc)
@@ -210,18 +221,15 @@ void free_scene(rthip_ctx* c) {
 // the per-frame work buffers: everything sized by the 8x8-tile slot count or the frame group
 void free_work_buffers(rthip_ctx* c) {
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream); // k_order_runs may still be reading the buffers freed below
-    c->order_pending = false;
+    for (auto& s : c->oset) { s.pending = false; s.runs = 0; free_dev_t(s.cost); free_dev_t(s.order); }
     free_dev_t(c->queue_mem); free_dev_t(c->hits); free_dev_t(c->partial); free_dev_t(c->spill); free_dev_t(c->shadow_mem);
     free_dev_t(c->cand_lists);
-    free_dev_t(c->path_cost);
-    free_dev_t(c->path_order);
     free_dev_t(c->path_plan);
     free_dev_t(c->path_perm);
     free_dev_t(c->tile_order);
     c->tile_order_cap = 0;
     c->tile_order_tiles = 0;
     c->path_runs_cap = 0;
-    c->order_runs = 0;
     c->cand_cap = 0;
     c->shadow_cap = 0;
     c->spill_words = 0;
@@ -534,7 +542,7 @@ void rthip_destroy(rthip_ctx* c) {
     free_frame_buffers(c);
     free_dev_t(c->ctrl);
     if (c->ev_path_done) (void)hipEventDestroy(c->ev_path_done);
-    if (c->ev_order_done) (void)hipEventDestroy(c->ev_order_done);
+    for (auto& s : c->oset) if (s.done) (void)hipEventDestroy(s.done);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     free_dev_t(c->d_counters);
     if (c->watchdog_host) (void)hipHostFree(c->watchdog_host);
@@ -1002,7 +1010,7 @@ int rthip_upload_scene(rthip_ctx* c, const rthip_scene_desc* s) {
     c->node_index_map.swap(map);
     c->have_scene = true;
     c->reject_hist = 1;
-    c->order_runs = 0; // what the runs of camera paths cost in the old scene says nothing about this one
+    for (auto& s : c->oset) s.runs = 0; // what the runs of camera paths cost in the old scene says nothing about this one
     c->tile_order_tiles = 0;
     return RTHIP_OK;
 }
@@ -1275,7 +1283,8 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 if (!c->side_stream && !c->side_failed) {
                     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
                         hipEventCreateWithFlags(&c->ev_path_done, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&c->ev_order_done, hipEventDisableTiming) != hipSuccess) {
+                        hipEventCreateWithFlags(&c->oset[0].done, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->oset[1].done, hipEventDisableTiming) != hipSuccess) {
                         (void)hipGetLastError();
                         if (c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
                         c->side_failed = true;
@@ -1289,35 +1298,57 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                     HIP_TRY(c, hipMalloc((void**)&c->tile_order, sizeof(uint32_t) * n_runs));
                     c->tile_order_cap = n_runs;
                 }
-                if (c->order_pending) { // the order this call hands out by is still being made
-                    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_order_done, 0));
-                    c->order_pending = false;
-                }
                 if (c->path_runs_cap < n_runs) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    free_dev_t(c->path_cost);
-                    free_dev_t(c->path_order);
+                    if (c->side_stream) HIP_TRY(c, hipStreamSynchronize(c->side_stream));
+                    for (auto& s : c->oset) { s.pending = false; s.runs = 0; free_dev_t(s.cost); free_dev_t(s.order); }
                     free_dev_t(c->path_plan);
                     free_dev_t(c->path_perm);
                     c->path_runs_cap = 0;
-                    c->order_runs = 0;
-                    HIP_TRY(c, hipMalloc((void**)&c->path_cost, sizeof(uint32_t) * n_runs));
-                    HIP_TRY(c, hipMalloc((void**)&c->path_order, sizeof(uint32_t) * (size_t)n_runs));
+                    for (auto& s : c->oset) {
+                        HIP_TRY(c, hipMalloc((void**)&s.cost, sizeof(uint32_t) * n_runs));
+                        HIP_TRY(c, hipMalloc((void**)&s.order, sizeof(uint32_t) * (size_t)n_runs));
+                    }
                     HIP_TRY(c, hipMalloc((void**)&c->path_plan, sizeof(uint32_t) * (2 * (size_t)n_runs + 2 * ((size_t)n_runs / RT_PLAN_BLOCK_RUNS + 1))));
                     HIP_TRY(c, hipMalloc((void**)&c->path_perm, sizeof(uint32_t) * 64 * (size_t)n_runs));
                     c->path_runs_cap = n_runs;
                 }
-                // (a call that discards the image keeps the order: while the camera moves every call
-                // discards, and what the tiles cost one frame ago still says more than nothing)
-                const bool same = c->order_runs == n_runs && c->order_res_x == c->res_x && c->order_res_y == c->res_y && c->order_frames == nf &&
-                                  c->order_spread == pa.gen.spread_shift && (keep_env != 0 || !overwrite);
-                if (!same) {
-                    hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, c->path_cost, c->path_order, n_runs);
-                    c->order_runs = n_runs; c->order_res_x = c->res_x; c->order_res_y = c->res_y; c->order_frames = nf; c->order_spread = pa.gen.spread_shift;
+                // This call's costs, and the order made from them behind it, go to set `mine`; `last` is
+                // what the call before wrote.  (A call that discards the image keeps the order: while
+                // the camera moves every call discards, and what the tiles cost a frame or two ago
+                // still says more than nothing.)
+                rthip_ctx::OrderSet& mine = c->oset[c->oset_turn];
+                rthip_ctx::OrderSet& last = c->oset[c->oset_turn ^ 1u];
+                auto fits = [&](const rthip_ctx::OrderSet& s) {
+                    return s.runs == n_runs && s.res_x == c->res_x && s.res_y == c->res_y && s.frames == nf && s.spread == pa.gen.spread_shift &&
+                           (keep_env != 0 || !overwrite);
+                };
+                auto wait_for = [&](rthip_ctx::OrderSet& s) -> hipError_t {
+                    if (!s.pending) return hipSuccess;
+                    s.pending = false;
+                    return hipStreamWaitEvent(c->stream, s.done, 0);
+                };
+                // (an event that has been reached needs no wait in the stream)
+                for (auto& s : c->oset)
+                    if (s.pending && hipEventQuery(s.done) == hipSuccess) s.pending = false;
+                (void)hipGetLastError(); // hipErrorNotReady is not an error here
+                // the kernels of this call read and write `mine`: whatever the side stream still does with it comes first
+                HIP_TRY(c, wait_for(mine));
+                const uint32_t* order = nullptr;
+                if (fits(last) && (!last.pending || !fits(mine))) {
+                    HIP_TRY(c, wait_for(last));      // made by now, or the only one there is
+                    order = last.order;
+                    if (!fits(mine)) hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, mine.cost, mine.order, n_runs); // clears the costs
+                } else if (fits(mine)) {
+                    order = mine.order;              // the call before is still being ordered: the order of the one before it
+                } else {
+                    hipLaunchKernelGGL(k_order_first, dim3((n_runs + 255u) / 256u), dim3(256), 0, c->stream, mine.cost, mine.order, n_runs);
+                    order = mine.order;              // a new shape or a new scene starts without costs
                 }
+                mine.runs = n_runs; mine.res_x = c->res_x; mine.res_y = c->res_y; mine.frames = nf; mine.spread = pa.gen.spread_shift;
                 PlanArgs pl{};
                 pl.gen = pa.gen;
-                pl.order = c->path_order;
+                pl.order = order;
                 pl.n_runs = n_runs;
                 pl.split = split;
                 pl.term_prob = P.term_prob;
@@ -1329,7 +1360,7 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                 hipLaunchKernelGGL(k_plan_count, dim3(plan_grid), dim3(1024), 0, c->stream, pl);
                 hipLaunchKernelGGL(k_plan_scatter, dim3(plan_grid), dim3(1024), 0, c->stream, pl);
                 pa.perm = c->path_perm;
-                pa.cost = c->path_cost;
+                pa.cost = mine.cost;
                 pa.n_slots = (uint32_t)(c->n_pixels * nf); // the slots that are inside the image
             }
 #ifdef RT_PROBE
@@ -1362,23 +1393,26 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
                                    (uint32_t)c->n_pixels, nf, overwrite ? 1u : 0u);
             }
             if (pa.cost) {
-                // the order of the next call: behind this launch, beside whatever the caller does next
+                // the order for the calls to come: behind this launch, beside whatever the caller does next
+                rthip_ctx::OrderSet& mine = c->oset[c->oset_turn];
                 hipStream_t os = c->stream;
-                if (c->side_stream && c->ev_path_done && c->ev_order_done) {
+                if (c->side_stream && c->ev_path_done && mine.done) {
                     HIP_TRY(c, hipEventRecord(c->ev_path_done, c->stream));
                     HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_path_done, 0));
                     os = c->side_stream;
                 }
-                hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, os, c->path_cost, c->path_order, n_runs);
+                hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, os, mine.cost, mine.order, n_runs);
                 if (nf == 1u && pa.gen.spread_shift == 0u && c->tile_order != nullptr && c->tile_order_cap >= n_runs) {
                     // one frame, whole tiles: the order of the runs is an order of the tiles; the staged pipeline keeps a copy
-                    HIP_TRY(c, hipMemcpyAsync(c->tile_order, c->path_order, sizeof(uint32_t) * n_runs, hipMemcpyDeviceToDevice, os));
+                    HIP_TRY(c, hipMemcpyAsync(c->tile_order, mine.order, sizeof(uint32_t) * n_runs, hipMemcpyDeviceToDevice, os));
                     c->tile_order_tiles = n_runs; c->tile_order_res_x = c->res_x; c->tile_order_res_y = c->res_y;
+                    c->tile_order_set = c->oset_turn;
                 }
                 if (os != c->stream) {
-                    HIP_TRY(c, hipEventRecord(c->ev_order_done, os));
-                    c->order_pending = true;
+                    HIP_TRY(c, hipEventRecord(mine.done, os));
+                    mine.pending = true;
                 }
+                c->oset_turn ^= 1u;
             }
             c->reject_hist = 0; // main.rs:403
             if (tap_group) c->taps_valid = true;
@@ -1386,9 +1420,10 @@ int rthip_render(rthip_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t
         }
         ga.tile_order = nullptr;
         if (tile_order_wanted && ga.spread_shift == 0u && have_tile_order()) {
-            if (c->order_pending) {
-                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_order_done, 0));
-                c->order_pending = false;
+            rthip_ctx::OrderSet& ts = c->oset[c->tile_order_set]; // (a later k_order_runs of the set only makes the wait longer)
+            if (ts.pending) {
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, ts.done, 0));
+                ts.pending = false;
             }
             ga.tile_order = c->tile_order;
         }
