@@ -95,7 +95,7 @@ typedef struct {
     uint64_t shadow_rays;     /* enable_sun only: trace_shadow calls, shader.wgsl:630-638       */
 } rthip_counters;
 
-#define RTHIP_STAGE_GENERATE 0
+#define RTHIP_STAGE_GENERATE 0   /* camera rays; no launch of its own where the cull stage makes them */
 #define RTHIP_STAGE_EXTEND   1
 #define RTHIP_STAGE_SHADE    2
 #define RTHIP_STAGE_RESOLVE  3
