@@ -555,6 +555,10 @@ int rthip_set_stream(rthip_ctx* c, void* hip_stream) {
     if (!c) return fail(nullptr, RTHIP_ERR_INVALID, "null context");
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->side_stream) { // what still runs behind the last call of the single launch ends before a new stream takes over
+        HIP_TRY(c, hipStreamSynchronize(c->side_stream));
+        for (auto& s : c->oset) s.pending = false;
+    }
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RTHIP_OK;
 }
