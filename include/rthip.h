@@ -14,7 +14,11 @@
  * Ownership: input pointers are borrowed for the duration of the call and copied to the
  * device; outputs are caller-allocated host buffers unless a parameter says "device".
  * Streams: every context owns one HIP stream; all work is enqueued there and calls that return
- * data synchronise it.  rthip_set_stream substitutes a caller's stream.
+ * data synchronise it.  rthip_set_stream substitutes a caller's stream.  A context that renders
+ * small frame groups also makes one non-blocking stream and three events of its own, at the first
+ * such call: a small kernel that only prepares later calls runs there, behind the call's launch and
+ * ordered against the calls by events, so the caller's synchronisation of its stream does not
+ * wait for it; rthip_set_stream and rthip_destroy do.
  */
 #ifndef RTHIP_H
 #define RTHIP_H
